@@ -1,0 +1,131 @@
+"""Synthetic, noise-free IMU derived from the camera trajectory through the probe
+kinematics (host side, NumPy; one sample per call).
+
+Formulas: kinematics/equations.py:8-41 (f_imu, f_imu_meas) evaluated in closed
+form; call protocol of models/Imu.py (87-97, 141-226, 305-315) kept so the
+reference-shaped ``Filter`` can drive it.  SURVEY.md App. A.1 steps 4-6.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+
+from . import rotmath as rm
+from .probe import SimpleProbe
+from .quaternion import Quaternion
+
+
+def imu_pose_from_camera(cam_vec, fwkin):
+    """f_imu (equations.py:8-13,54-60): IMU position, attitude, velocity in W."""
+    W_p_CW, R_WC, WW_v_CW, W_om_CW, _, _ = (np.asarray(a, dtype=float) for a in cam_vec)
+    B_p_CB, R_BC, BB_v_CB, B_om_CB, _, _ = fwkin
+    R_WB = R_WC @ R_BC.T
+    W_om_BW = W_om_CW.reshape(3) - R_WB @ B_om_CB
+    lever = R_WB @ B_p_CB
+    W_p_BW = W_p_CW.reshape(3) - lever
+    WW_v_BW = WW_v_CW.reshape(3) - R_WB @ BB_v_CB - np.cross(W_om_BW, lever)
+    return W_p_BW, R_WB, WW_v_BW
+
+
+def imu_measurement(R_WC, W_om_CW, W_acc_CW, W_alp_CW, fwkin):
+    """f_imu_meas (equations.py:15-41,63-69): body-frame angular rate and
+    acceleration; no gravity, bias or noise."""
+    B_p_CB, R_BC, BB_v_CB, B_om_CB, B_acc_CB, B_alp_CB = fwkin
+    R_WB = np.asarray(R_WC, dtype=float) @ R_BC.T
+    om_c = np.asarray(W_om_CW, dtype=float).reshape(3)
+    W_om = om_c - R_WB @ B_om_CB
+    lever = R_WB @ B_p_CB
+    om_x_lever = np.cross(W_om, lever)
+    W_alp = np.asarray(W_alp_CW, dtype=float).reshape(3) - R_WB @ B_alp_CB - np.cross(W_om, R_WB @ B_om_CB)
+    W_acc = (np.asarray(W_acc_CW, dtype=float).reshape(3) - R_WB @ B_acc_CB
+             - 2 * np.cross(W_om, R_WB @ BB_v_CB) - np.cross(W_alp, lever) - np.cross(W_om, om_x_lever))
+    return R_WB.T @ W_om, R_WB.T @ W_acc
+
+
+class ImuRefTraj:
+    """Desired IMU trajectory log, 14 columns (trajectory/ImuRefTraj.py:18-55)."""
+
+    labels = ["t", "x", "y", "z", "vx", "vy", "vz", "rx", "ry", "rz", "qw", "qx", "qy", "qz"]
+
+    def __init__(self, name: str, imu: "Imu"):
+        self.name = name
+        self._imu = imu
+        self.reset()
+
+    def reset(self) -> None:
+        for lab in self.labels:
+            setattr(self, lab, None)
+
+    @property
+    def num_values(self) -> int:
+        return 0 if self.t is None else len(self.t)
+
+    def append_value(self, t: float, cam_meas_vec, current_notch) -> None:
+        p, R_WB, v = self._imu.ref_vals(cam_meas_vec, current_notch)
+        q = Quaternion(val=R_WB, do_normalise=True)
+        # scipy from_matrix(...).as_euler on the (orthonormal) product R_WC R_BC^T
+        data = [t, *p, *v, *q.euler_xyz_deg, *q.wxyz]
+        for i, lab in enumerate(self.labels):
+            if getattr(self, lab) is None:
+                setattr(self, lab, [data[i]])
+            else:
+                getattr(self, lab).append(data[i])
+
+
+class Imu:
+    def __init__(self, probe: SimpleProbe, cam, stdev_na=None, stdev_nom=None, gen_ref: bool = False):
+        self.stdev_na = stdev_na
+        self.stdev_nom = stdev_nom
+        self.probe = probe
+        self.cam = cam            # interpolated camera
+        self.t: List[float] = []
+        self._om: List[np.ndarray] = []
+        self._acc: List[np.ndarray] = []
+        self.ref: Optional[ImuRefTraj] = ImuRefTraj("imu ref", self) if gen_ref else None
+
+    @staticmethod
+    def create(config, camera, probe, gen_ref: bool = False) -> "Imu":
+        """Imu.create (Imu.py:87-97): ``config`` is the ImuConfig in the reference;
+        any object with interframe_vals/stdev_accel/stdev_omega works."""
+        return Imu(probe, camera.interpolate(config.interframe_vals), config.stdev_accel,
+                   config.stdev_omega, gen_ref=gen_ref)
+
+    def reset(self) -> None:
+        self.t, self._om, self._acc = [], [], []
+        if self.ref is not None:
+            self.ref.reset()
+
+    @property
+    def om(self) -> np.ndarray:
+        return np.array(self._om).T
+
+    @property
+    def acc(self) -> np.ndarray:
+        return np.array(self._acc).T
+
+    def eval_expr_single(self, t, q, qd, qdd, W_acc_C, R_WC, W_om_C, W_alp_C,
+                         append_array: bool = False, filepath: str = "", overwrite: bool = False):
+        """Imu.eval_expr_single (Imu.py:141-196): q/qd/qdd are the 8 joint values,
+        of which only the notch entries [6] vary."""
+        from .probe import probe_fwkin
+        fk = probe_fwkin(q[:6], (q[6], qd[6], qdd[6]), self.probe.scope_length, self.probe.theta_cam)
+        res_om, res_acc = imu_measurement(R_WC, W_om_C, W_acc_C, W_alp_C, fk)
+        if append_array:
+            self.t.append(t)
+            self._om.append(res_om)
+            self._acc.append(res_acc)
+        if overwrite:
+            self.t, self._om, self._acc = [t], [res_om], [res_acc]
+        return res_om, res_acc
+
+    def eval_init(self, probe_joint_dofs, notch_dofs, overwrite: bool = False) -> None:
+        """Imu.eval_init (Imu.py:198-226): IMU sample at interpolated index 0."""
+        q0, qd0, qdd0 = probe_joint_dofs
+        q0[6], qd0[6], qdd0[6] = notch_dofs
+        self.eval_expr_single(self.cam.t[0], q0, qd0, qdd0, self.cam.acc[:, 0], self.cam.R[0],
+                              self.cam.om[:, 0], self.cam.alp[:, 0], append_array=True, overwrite=overwrite)
+
+    def ref_vals(self, cam_meas_vec, current_notch):
+        """Imu.ref_vals (Imu.py:305-315): W_p_BW, R_WB, WW_v_BW."""
+        return list(imu_pose_from_camera(cam_meas_vec, self.probe.fwkin(current_notch)))
