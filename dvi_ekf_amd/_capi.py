@@ -1,0 +1,77 @@
+"""ctypes binding of libdvi_eskf.so (include/dvi_eskf.h).
+
+The shared library is the product: if it is missing or does not export every
+entry point, importing this module's ``lib()`` raises -- there is no CPU or
+PyTorch fallback for the filter arithmetic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvi_eskf.so")
+
+F64, F32 = 0, 1
+STATUS_SINGULAR, STATUS_NONFINITE = 1, 2
+
+
+class Params(C.Structure):
+    """dvi_eskf_params"""
+    _fields_ = [
+        ("L", C.c_double), ("theta_cam", C.c_double), ("frozen", C.c_int32 * 6), ("hold_frozen", C.c_int32),
+        ("sigma_a", C.c_double * 3), ("sigma_om", C.c_double * 3),
+    ]
+
+
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+_dp = C.POINTER(C.c_double)
+_hpp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/dvi_eskf.h one to one
+SIGNATURES = {
+    "dvi_eskf_create": (_i, [C.POINTER(Params), _i64, _i, _i, _hpp]),
+    "dvi_eskf_clone": (_i, [_vp, _vp, _hpp]),
+    "dvi_eskf_destroy": (None, [_vp]),
+    "dvi_eskf_batch": (_i64, [_vp]),
+    "dvi_eskf_dtype": (_i, [_vp]),
+    "dvi_eskf_set_noise": (_i, [_vp, _dp, _dp]),
+    "dvi_eskf_set_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dvi_eskf_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dvi_eskf_predict": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "dvi_eskf_update": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dvi_eskf_step": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dvi_eskf_epoch": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dvi_eskf_get_calibration": (_i, [_vp, _vp, _vp]),
+    "dvi_eskf_raw_P": (_vp, [_vp]),
+    "dvi_eskf_raw_x": (_vp, [_vp]),
+    "dvi_eskf_set_lanes_per_instance": (_i, [_vp, _i]),
+    "dvi_eskf_strerror": (C.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP library is required (build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C dvi_ekf_amd/csrc`)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class EskfError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise EskfError(f"{what}: {lib().dvi_eskf_strerror(code).decode()} ({code})")

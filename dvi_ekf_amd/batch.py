@@ -1,0 +1,217 @@
+"""``BatchedESKF`` -- a batch of independent filter instances living on one
+MI355X, driven through the C ABI (include/dvi_eskf.h).  PyTorch is used only as
+the owner of device buffers and the source of the HIP stream.
+
+Per-instance semantics are those of the reference's ``Filter.propagate`` /
+``Filter.update`` (Filter.py:219-395).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedESKF:
+    def __init__(self, batch: int, *, length: float, theta_cam: float, frozen: Sequence[int],
+                 sigma_a, sigma_om, hold_frozen: bool = False, dtype: torch.dtype = torch.float64,
+                 device: Optional[torch.device] = None, _handle=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedESKF needs a HIP device: the filter arithmetic only exists as HIP kernels")
+        self.lib = _capi.lib()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError("device must be a HIP (cuda:N) device")
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("dtype must be float64 or float32")
+        self.dtype = dtype
+        self.batch = int(batch)
+        self._prm = dict(length=float(length), theta_cam=float(theta_cam), frozen=[int(bool(f)) for f in frozen],
+                         sigma_a=[float(v) for v in sigma_a], sigma_om=[float(v) for v in sigma_om],
+                         hold_frozen=bool(hold_frozen))
+        self.Q = np.eye(13)
+        self.R = np.eye(7)
+        if _handle is not None:
+            self._h = _handle
+            return
+        p = _capi.Params()
+        p.L, p.theta_cam, p.hold_frozen = self._prm["length"], self._prm["theta_cam"], int(hold_frozen)
+        p.frozen[:] = self._prm["frozen"]
+        p.sigma_a[:] = self._prm["sigma_a"]
+        p.sigma_om[:] = self._prm["sigma_om"]
+        h = C.c_void_p()
+        _capi.check(self.lib.dvi_eskf_create(C.byref(p), self.batch, _capi.F64 if dtype == torch.float64 else _capi.F32,
+                                             self.device.index or 0, C.byref(h)), "dvi_eskf_create")
+        self._h = h
+
+    # -- lifetime --------------------------------------------------------------------
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and getattr(self, "lib", None) is not None:
+            self.lib.dvi_eskf_destroy(h)
+            self._h = None
+
+    def clone(self) -> "BatchedESKF":
+        """copy.deepcopy semantics (Simulator.py:150): independent device buffers."""
+        h = C.c_void_p()
+        _capi.check(self.lib.dvi_eskf_clone(self._h, self._stream(), C.byref(h)), "dvi_eskf_clone")
+        other = BatchedESKF(self.batch, dtype=self.dtype, device=self.device, _handle=h, **self._prm)
+        other.Q, other.R = self.Q.copy(), self.R.copy()
+        return other
+
+    def __deepcopy__(self, memo):
+        return self.clone()
+
+    # -- helpers ---------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, shape_tail, allow_broadcast=True):
+        """Returns (tensor, per_instance flag).  A tensor already on the device with the
+        right dtype is used as is (zero copy)."""
+        if a is None:
+            return None, 0
+        t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+        t = t.to(device=self.device, dtype=self.dtype).contiguous()
+        tail = tuple(shape_tail)
+        if t.shape == (self.batch, *tail):
+            return t, 1
+        if allow_broadcast and (t.shape == tail or t.shape == (1, *tail) or (tail == () and t.numel() == 1)):
+            return t.reshape((1, *tail)), 0
+        raise ValueError(f"expected shape {(self.batch, *tail)} or {tail}, got {tuple(t.shape)}")
+
+    def set_lanes_per_instance(self, lanes: int) -> None:
+        _capi.check(self.lib.dvi_eskf_set_lanes_per_instance(self._h, int(lanes)), "set_lanes_per_instance")
+
+    # -- noise / state ----------------------------------------------------------------
+    def set_noise(self, Q=None, R=None) -> None:
+        """Filter.Q / Filter.R (Filter.py:67-75,110-117); both must be diagonal."""
+        dp = C.POINTER(C.c_double)
+        q = None if Q is None else np.ascontiguousarray(np.asarray(Q, dtype=np.float64).reshape(13, 13))
+        r = None if R is None else np.ascontiguousarray(np.asarray(R, dtype=np.float64).reshape(7, 7))
+        _capi.check(self.lib.dvi_eskf_set_noise(self._h, None if q is None else q.ctypes.data_as(dp),
+                                                None if r is None else r.ctypes.data_as(dp)), "dvi_eskf_set_noise")
+        if q is not None:
+            self.Q = q.copy()
+        if r is not None:
+            self.R = r.copy()
+
+    def set_state(self, x=None, P=None, om_old=None, acc_old=None, q_old=None) -> None:
+        tx, _ = self._bcast(x, (26,))
+        tP, _ = self._bcast(P, (24, 24))
+        to, _ = self._bcast(om_old, (3,))
+        ta, _ = self._bcast(acc_old, (3,))
+        tq, _ = self._bcast(q_old, (4,))
+        _capi.check(self.lib.dvi_eskf_set_state(self._h, _ptr(tx), _ptr(tP), _ptr(to), _ptr(ta), _ptr(tq),
+                                                self._stream()), "dvi_eskf_set_state")
+
+    def _bcast(self, a, tail):
+        if a is None:
+            return None, 0
+        t, per = self._dev(a, tail)
+        if not per:
+            t = t.expand(self.batch, *tail).contiguous()
+        return t, 1
+
+    def get_state(self, what=("x", "P", "om_old", "acc_old", "q_old")):
+        out = {}
+        mk = lambda *s: torch.empty((self.batch, *s), dtype=self.dtype, device=self.device)
+        bufs = {"x": mk(26) if "x" in what else None, "P": mk(24, 24) if "P" in what else None,
+                "om_old": mk(3) if "om_old" in what else None, "acc_old": mk(3) if "acc_old" in what else None,
+                "q_old": mk(4) if "q_old" in what else None}
+        _capi.check(self.lib.dvi_eskf_get_state(self._h, _ptr(bufs["x"]), _ptr(bufs["P"]), _ptr(bufs["om_old"]),
+                                                _ptr(bufs["acc_old"]), _ptr(bufs["q_old"]), self._stream()),
+                    "dvi_eskf_get_state")
+        for k in what:
+            out[k] = bufs[k]
+        return out
+
+    @property
+    def x(self) -> torch.Tensor:
+        return self.get_state(("x",))["x"]
+
+    @property
+    def P(self) -> torch.Tensor:
+        return self.get_state(("P",))["P"]
+
+    def calibration(self) -> torch.Tensor:
+        """Estimated extrinsic DOFs [B,6] (state.dofs)."""
+        out = torch.empty((self.batch, 6), dtype=self.dtype, device=self.device)
+        _capi.check(self.lib.dvi_eskf_get_calibration(self._h, _ptr(out), self._stream()), "dvi_eskf_get_calibration")
+        return out
+
+    # -- the hot path -------------------------------------------------------------------
+    def predict(self, dt, om, acc) -> None:
+        """Filter.propagate (Filter.py:219-230) for every instance."""
+        tdt, pdt = self._dev(dt, ())
+        tom, pim = self._dev(om, (3,))
+        tac, pa = self._dev(acc, (3,))
+        if pim != pa:
+            raise ValueError("om and acc must both be per-instance or both broadcast")
+        _capi.check(self.lib.dvi_eskf_predict(self._h, _ptr(tdt), pdt, _ptr(tom), _ptr(tac), pim, self._stream()),
+                    "dvi_eskf_predict")
+
+    def _meas(self, pos, quat, notch):
+        tp, pp = self._dev(pos, (3,))
+        tq, pq = self._dev(quat, (4,))
+        tn, pn = self._dev(notch, ())
+        if not (pp == pq == pn):
+            if pp or pq or pn:   # mixed: expand the broadcast ones
+                tp, _ = self._bcast(tp if pp else tp.reshape(3), (3,))
+                tq, _ = self._bcast(tq if pq else tq.reshape(4), (4,))
+                tn, _ = self._bcast(tn if pn else tn.reshape(()), ())
+                pp = 1
+        return tp, tq, tn, pp
+
+    def update(self, pos, quat, notch, want_gain: bool = False):
+        """Filter.update (Filter.py:351-395).  Returns (status[B] int32, K[B,24,7] | None)."""
+        tp, tq, tn, per = self._meas(pos, quat, notch)
+        K = torch.empty((self.batch, 24, 7), dtype=self.dtype, device=self.device) if want_gain else None
+        status = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+        _capi.check(self.lib.dvi_eskf_update(self._h, _ptr(tp), _ptr(tq), _ptr(tn), per, _ptr(K), _ptr(status),
+                                             self._stream()), "dvi_eskf_update")
+        return status, K
+
+    def step(self, dt, om, acc, pos, quat, notch, want_gain: bool = False, status: Optional[torch.Tensor] = None):
+        """One predict + one update in a single launch."""
+        tdt, pdt = self._dev(dt, ())
+        tom, pim = self._dev(om, (3,))
+        tac, pa = self._dev(acc, (3,))
+        if pim != pa:
+            raise ValueError("om and acc must both be per-instance or both broadcast")
+        tp, tq, tn, per = self._meas(pos, quat, notch)
+        K = torch.empty((self.batch, 24, 7), dtype=self.dtype, device=self.device) if want_gain else None
+        if status is None:
+            status = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+        _capi.check(self.lib.dvi_eskf_step(self._h, _ptr(tdt), pdt, _ptr(tom), _ptr(tac), pim, _ptr(tp), _ptr(tq),
+                                           _ptr(tn), per, _ptr(K), _ptr(status), self._stream()), "dvi_eskf_step")
+        return status, K
+
+    def epoch(self, dt, om, acc, pos, quat, notch, want_gain: bool = False):
+        """n predicts then one update in a single launch (Filter.run_one_epoch).
+        dt [n] | [n,B]; om/acc [n,3] | [n,B,3]."""
+        tdt = torch.as_tensor(np.asarray(dt) if not isinstance(dt, torch.Tensor) else dt).to(self.device, self.dtype)
+        tom = torch.as_tensor(np.asarray(om) if not isinstance(om, torch.Tensor) else om).to(self.device, self.dtype)
+        tac = torch.as_tensor(np.asarray(acc) if not isinstance(acc, torch.Tensor) else acc).to(self.device, self.dtype)
+        tdt, tom, tac = tdt.contiguous(), tom.contiguous(), tac.contiguous()
+        n = tdt.shape[0]
+        pdt = 1 if tdt.dim() == 2 else 0
+        pim = 1 if tom.dim() == 3 else 0
+        if pdt and tdt.shape != (n, self.batch):
+            raise ValueError("dt must be [n] or [n,B]")
+        if tom.shape != ((n, self.batch, 3) if pim else (n, 3)) or tac.shape != tom.shape:
+            raise ValueError("om/acc must be [n,3] or [n,B,3]")
+        tp, tq, tn, per = self._meas(pos, quat, notch)
+        K = torch.empty((self.batch, 24, 7), dtype=self.dtype, device=self.device) if want_gain else None
+        status = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+        _capi.check(self.lib.dvi_eskf_epoch(self._h, n, _ptr(tdt), pdt, _ptr(tom), _ptr(tac), pim, _ptr(tp), _ptr(tq),
+                                            _ptr(tn), per, _ptr(K), _ptr(status), self._stream()), "dvi_eskf_epoch")
+        return status, K

@@ -1,0 +1,227 @@
+// eskf_capi.cpp -- C ABI (include/dvi_eskf.h) over the HIP kernels.  Owns the device
+// records of a batch of filter instances; never throws, never frees caller memory.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "../../include/dvi_eskf.h"
+#include "eskf_device.h"
+
+struct dvi_eskf {
+    int64_t B;
+    int dtype;
+    int device;
+    int lpi;
+    eskf::HostParams hp;
+    void* d_P;   // [B][300]
+    void* d_x;   // [B][36]
+};
+
+namespace {
+
+size_t elem_size(int dtype) { return dtype == DVI_ESKF_F64 ? sizeof(double) : sizeof(float); }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_pi, const void* om, const void* acc,
+                int imu_pi, const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out,
+                int32_t* status, void* stream) {
+    if (!h) return DVI_ESKF_EINVAL;
+    if (n_pred < 0) return DVI_ESKF_EINVAL;
+    if (n_pred > 0 && (!dt || !om || !acc)) return DVI_ESKF_EINVAL;
+    if (do_update && (!pos || !quat || !notch)) return DVI_ESKF_EINVAL;
+    if (n_pred == 0 && !do_update) return DVI_ESKF_OK;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    eskf::StepArgs a;
+    a.P = h->d_P; a.xs = h->d_x;
+    a.dt = dt; a.om = om; a.acc = acc;
+    a.pos = pos; a.quat = quat; a.notch = notch;
+    a.K_out = do_update ? K_out : nullptr;
+    a.status = do_update ? status : nullptr;
+    a.B = h->B;
+    a.n_pred = n_pred;
+    a.do_update = do_update ? 1 : 0;
+    a.dt_stride = dt_pi ? 1 : 0;
+    a.imu_stride = imu_pi ? 1 : 0;
+    a.meas_stride = meas_pi ? 1 : 0;
+    hipError_t e = eskf::launch_step(h->dtype, h->lpi, a, h->hp, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int device, dvi_eskf** out) {
+    if (!p || !out || batch <= 0) return DVI_ESKF_EINVAL;
+    if (dtype != DVI_ESKF_F64 && dtype != DVI_ESKF_F32) return DVI_ESKF_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DVI_ESKF_ENODEV;
+    DeviceGuard g(device);
+    if (!g.ok) return DVI_ESKF_ENODEV;
+    dvi_eskf* h = new (std::nothrow) dvi_eskf();
+    if (!h) return DVI_ESKF_ENOMEM;
+    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 12;
+    h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
+    h->hp.frozen_mask = 0;
+    for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);
+    h->hp.hold_frozen = p->hold_frozen ? 1 : 0;
+    for (int i = 0; i < 3; ++i) { h->hp.sig_a[i] = p->sigma_a[i]; h->hp.sig_om[i] = p->sigma_om[i]; }
+    for (int i = 0; i < 13; ++i) h->hp.qd[i] = 1.0;   // Q = eye before set_noise (Filter.py:68)
+    for (int i = 0; i < 7; ++i) h->hp.r[i] = 1.0;
+    const size_t es = elem_size(dtype);
+    h->d_P = nullptr; h->d_x = nullptr;
+    if (hipMalloc(&h->d_P, (size_t)batch * 300 * es) != hipSuccess ||
+        hipMalloc(&h->d_x, (size_t)batch * 36 * es) != hipSuccess) {
+        if (h->d_P) (void)hipFree(h->d_P);
+        delete h;
+        return DVI_ESKF_ENOMEM;
+    }
+    (void)hipMemset(h->d_P, 0, (size_t)batch * 300 * es);
+    (void)hipMemset(h->d_x, 0, (size_t)batch * 36 * es);
+    *out = h;
+    return DVI_ESKF_OK;
+}
+
+int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
+    if (!src || !out) return DVI_ESKF_EINVAL;
+    *out = nullptr;
+    DeviceGuard g(src->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    dvi_eskf* h = new (std::nothrow) dvi_eskf(*src);
+    if (!h) return DVI_ESKF_ENOMEM;
+    const size_t es = elem_size(src->dtype);
+    h->d_P = nullptr; h->d_x = nullptr;
+    if (hipMalloc(&h->d_P, (size_t)src->B * 300 * es) != hipSuccess ||
+        hipMalloc(&h->d_x, (size_t)src->B * 36 * es) != hipSuccess) {
+        if (h->d_P) (void)hipFree(h->d_P);
+        delete h;
+        return DVI_ESKF_ENOMEM;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(h->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(h->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        (void)hipFree(h->d_P); (void)hipFree(h->d_x);
+        delete h;
+        return DVI_ESKF_EHIP;
+    }
+    *out = h;
+    return DVI_ESKF_OK;
+}
+
+void dvi_eskf_destroy(dvi_eskf* h) {
+    if (!h) return;
+    DeviceGuard g(h->device);
+    if (h->d_P) (void)hipFree(h->d_P);
+    if (h->d_x) (void)hipFree(h->d_x);
+    delete h;
+}
+
+int64_t dvi_eskf_batch(const dvi_eskf* h) { return h ? h->B : 0; }
+int dvi_eskf_dtype(const dvi_eskf* h) { return h ? h->dtype : DVI_ESKF_EINVAL; }
+
+int dvi_eskf_set_noise(dvi_eskf* h, const double* Q, const double* R) {
+    if (!h) return DVI_ESKF_EINVAL;
+    if (Q) {
+        for (int i = 0; i < 13; ++i)
+            for (int j = 0; j < 13; ++j)
+                if (i != j && Q[i * 13 + j] != 0.0) return DVI_ESKF_EINVAL;
+        for (int i = 0; i < 13; ++i) if (!std::isfinite(Q[i * 13 + i])) return DVI_ESKF_EINVAL;
+    }
+    if (R) {
+        for (int i = 0; i < 7; ++i)
+            for (int j = 0; j < 7; ++j)
+                if (i != j && R[i * 7 + j] != 0.0) return DVI_ESKF_EINVAL;
+        for (int i = 0; i < 7; ++i) if (!std::isfinite(R[i * 7 + i])) return DVI_ESKF_EINVAL;
+    }
+    if (Q) for (int i = 0; i < 13; ++i) h->hp.qd[i] = Q[i * 13 + i];
+    if (R) for (int i = 0; i < 7; ++i) h->hp.r[i] = R[i * 7 + i];
+    return DVI_ESKF_OK;
+}
+
+int dvi_eskf_set_state(dvi_eskf* h, const void* x26, const void* P576, const void* om3, const void* acc3,
+                       const void* qo4, void* stream) {
+    if (!h) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_pack(h->dtype, h->B, x26, P576, om3, acc3, qo4, h->d_x, h->d_P, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
+int dvi_eskf_get_state(const dvi_eskf* h, void* x26, void* P576, void* om3, void* acc3, void* qo4, void* stream) {
+    if (!h) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_unpack(h->dtype, h->B, h->d_x, h->d_P, x26, P576, om3, acc3, qo4, nullptr,
+                                       (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
+int dvi_eskf_get_calibration(const dvi_eskf* h, void* dofs_out, void* stream) {
+    if (!h || !dofs_out) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_unpack(h->dtype, h->B, h->d_x, h->d_P, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                       dofs_out, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
+int dvi_eskf_predict(dvi_eskf* h, const void* dt, int dt_pi, const void* om, const void* acc, int imu_pi,
+                     void* stream) {
+    return step_common(h, 1, 0, dt, dt_pi, om, acc, imu_pi, nullptr, nullptr, nullptr, 0, nullptr, nullptr, stream);
+}
+
+int dvi_eskf_update(dvi_eskf* h, const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out,
+                    int32_t* status, void* stream) {
+    return step_common(h, 0, 1, nullptr, 0, nullptr, nullptr, 0, pos, quat, notch, meas_pi, K_out, status, stream);
+}
+
+int dvi_eskf_step(dvi_eskf* h, const void* dt, int dt_pi, const void* om, const void* acc, int imu_pi,
+                  const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out, int32_t* status,
+                  void* stream) {
+    return step_common(h, 1, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream);
+}
+
+int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_pi, const void* om, const void* acc, int imu_pi,
+                   const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out, int32_t* status,
+                   void* stream) {
+    return step_common(h, n_pred, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream);
+}
+
+void* dvi_eskf_raw_P(dvi_eskf* h) { return h ? h->d_P : nullptr; }
+void* dvi_eskf_raw_x(dvi_eskf* h) { return h ? h->d_x : nullptr; }
+
+int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes) {
+    if (!h) return DVI_ESKF_EINVAL;
+    if (lanes != 64 && lanes != 32 && lanes != 16 && lanes != 12 && lanes != 8) return DVI_ESKF_EINVAL;
+    h->lpi = lanes;
+    return DVI_ESKF_OK;
+}
+
+const char* dvi_eskf_strerror(int code) {
+    switch (code) {
+        case DVI_ESKF_OK: return "ok";
+        case DVI_ESKF_EINVAL: return "invalid argument";
+        case DVI_ESKF_ENODEV: return "no usable HIP device";
+        case DVI_ESKF_ENOMEM: return "device memory allocation failed";
+        case DVI_ESKF_EHIP: return "HIP runtime call or kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+}  // extern "C"

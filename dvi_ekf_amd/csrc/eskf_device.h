@@ -1,0 +1,73 @@
+// eskf_device.h -- types shared by the HIP kernels (eskf_kernels.hip) and the C-ABI
+// host layer (eskf_capi.cpp).  Internal; the public interface is include/dvi_eskf.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace eskf {
+
+constexpr int DVI_STATUS_SINGULAR = 1;
+constexpr int DVI_STATUS_NONFINITE = 2;
+
+// constants of one filter configuration, in the kernel's working precision; passed by value
+// as a kernel argument (lives in SGPRs / the kernarg segment)
+template <typename T>
+struct DevParams {
+    T L, st, ct;        // probe length, sin / cos of the camera angle
+    T sig_om[3];        // gyro noise std (Jacobian evaluation point, Filter.py:330-333)
+    T qd[13];           // diag(Q)  (Filter.py:68-72)
+    T r[7];             // diag(R)  (Filter.py:75)
+    int frozen_mask;    // bit i: DOF i frozen
+    int hold_frozen;    // 0: zero frozen DOFs after predict (Filter.py:243-245); 1: hold
+    int q_gyro;         // diag(Q)[3:6] has a non-zero entry
+};
+
+struct HostParams {
+    double L, theta_cam;
+    double sig_a[3], sig_om[3];
+    double qd[13], r[7];
+    int frozen_mask, hold_frozen;
+};
+
+template <typename T>
+inline DevParams<T> make_dev_params(const HostParams& h) {
+    DevParams<T> d;
+    d.L = (T)h.L;
+    d.st = (T)sin(h.theta_cam);
+    d.ct = (T)cos(h.theta_cam);
+    for (int i = 0; i < 3; ++i) d.sig_om[i] = (T)h.sig_om[i];
+    for (int i = 0; i < 13; ++i) d.qd[i] = (T)h.qd[i];
+    for (int i = 0; i < 7; ++i) d.r[i] = (T)h.r[i];
+    d.frozen_mask = h.frozen_mask;
+    d.hold_frozen = h.hold_frozen;
+    d.q_gyro = (h.qd[3] != 0.0 || h.qd[4] != 0.0 || h.qd[5] != 0.0) ? 1 : 0;
+    return d;
+}
+
+// arguments of one launch of the step kernel: n_pred predicts followed by an optional update
+struct StepArgs {
+    void* P;            // [B][300] packed covariance
+    void* xs;           // [B][36]  state record
+    const void* dt;     // [n_pred][B] (dt_stride = 1) or [n_pred]
+    const void* om;     // [n_pred][B][3] (imu_stride = 1) or [n_pred][3]
+    const void* acc;
+    const void* pos;    // [B][3] (meas_stride = 1) or [3]
+    const void* quat;   // [B][4] or [4]
+    const void* notch;  // [B] or [1]
+    void* K_out;        // nullable [B][24][7]
+    int32_t* status;    // nullable [B]
+    int64_t B;
+    int n_pred;
+    int do_update;
+    int dt_stride, imu_stride, meas_stride;
+};
+
+hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
+hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
+                       const void* qo4, void* xs, void* Ppk, hipStream_t stream);
+hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,
+                         void* acc3, void* qo4, void* dofs6, hipStream_t stream);
+
+}  // namespace eskf

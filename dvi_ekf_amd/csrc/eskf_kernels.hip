@@ -1,0 +1,866 @@
+// eskf_kernels.hip -- CDNA4 (gfx950) kernels of the batched error-state Kalman filter.
+//
+// Replaces, per filter instance, the per-step arithmetic of the reference's
+// Filter.propagate / Filter.update (dvi_ekf/filter/Filter.py:219-395) including the
+// CasADi-evaluated Jacobians (Filter.py:270-342, kinematics/symbols.py:134-200) and the
+// probe forward kinematics (models/Probe.py:147-167,431-480), in closed form
+// (SURVEY.md App. A/B).
+//
+// Execution model: a 64-thread block is ONE wavefront.  The wavefront hosts
+// G = 64 / LPI filter instances, LPI lanes each (LPI = 12 -> 5 instances per wave;
+// LPI = 64 -> the one-wavefront-per-instance layout).  Each instance owns a private LDS
+// region holding its 24x24 covariance (row stride 25 so that row- and column-owner
+// accesses are both bank-conflict free), a 6x24 / 24x7 scratch panel and its state.
+// The instance's "scalar" work (nominal propagation, Jacobian blocks, residual,
+// injection) is evaluated redundantly by its LPI lanes and stays in registers; the
+// matrix work is split over the lanes by ownership of columns / rows so that each
+// phase needs no intra-phase synchronisation.
+//
+// HBM layout (batch-major, one contiguous record per instance -- a wave reads whole
+// records, i.e. contiguous 2.4 KB / 288 B segments):
+//   P  [B][300]  symmetric-packed: 12 "double rows" r of 25 words, word c of double row
+//                r is P[r][c] for c <= r, else P[23-r][c-r-1]
+//   xs [B][36]   x26 | om_old3 | acc_old3 | q_old4   (R_WB_old = Rm(q_old), Filter.py:227)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eskf_device.h"
+
+namespace eskf {
+
+// ----------------------------------------------------------------------------------
+// small math on register arrays
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ void t_sincos(double a, double& s, double& c) { sincos(a, &s, &c); }
+__device__ __forceinline__ void t_sincos(float a, float& s, float& c) { sincosf(a, &s, &c); }
+__device__ __forceinline__ double t_sqrt(double a) { return sqrt(a); }
+__device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
+__device__ __forceinline__ double t_asin(double a) { return asin(a); }
+__device__ __forceinline__ float t_asin(float a) { return asinf(a); }
+__device__ __forceinline__ bool t_finite(double a) { return isfinite(a); }
+__device__ __forceinline__ bool t_finite(float a) { return isfinite(a); }
+
+template <typename T>
+__device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <typename T>
+__device__ __forceinline__ void mat3_vec(const T* A, const T* x, T* y) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+}
+template <typename T>
+__device__ __forceinline__ void mat3T_vec(const T* A, const T* x, T* y) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) y[i] = A[i] * x[0] + A[3 + i] * x[1] + A[6 + i] * x[2];
+}
+// C = A * [w]x   (columns of the result are A (e_k x ... ) -- written out)
+template <typename T>
+__device__ __forceinline__ void mat3_skew(const T* A, const T* w, T* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T a0 = A[3 * i], a1 = A[3 * i + 1], a2 = A[3 * i + 2];
+        C[3 * i + 0] = a1 * w[2] - a2 * w[1];
+        C[3 * i + 1] = a2 * w[0] - a0 * w[2];
+        C[3 * i + 2] = a0 * w[1] - a1 * w[0];
+    }
+}
+// Quaternion.rot (tools/Quaternion.py:101-107): rotation matrix of q/|q|, xyzw
+template <typename T>
+__device__ __forceinline__ void quat_to_mat(const T* q, T* M) {
+    const T n = T(1) / t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const T x = q[0] * n, y = q[1] * n, z = q[2] * n, w = q[3] * n;
+    const T x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w;
+    const T xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+    M[0] = x2 - y2 - z2 + w2; M[1] = T(2) * (xy - zw);   M[2] = T(2) * (xz + yw);
+    M[3] = T(2) * (xy + zw);  M[4] = -x2 + y2 - z2 + w2; M[5] = T(2) * (yz - xw);
+    M[6] = T(2) * (xz - yw);  M[7] = T(2) * (yz + xw);   M[8] = -x2 - y2 + z2 + w2;
+}
+// Quaternion.normalise (Quaternion.py:195-206): unit length, scalar part >= 0
+template <typename T>
+__device__ __forceinline__ void quat_nrm(T* q) {
+    T n = T(1) / t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (q[3] < T(0)) n = -n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] *= n;
+}
+// Hamilton product xyzw (Quaternion.py:170-173)
+template <typename T>
+__device__ __forceinline__ void quat_mul(const T* a, const T* b, T* o) {
+    T c[3];
+    cross3(a, b, c);
+    o[3] = a[3] * b[3] - (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = a[3] * b[i] + b[3] * a[i] + c[i];
+}
+// Quaternion(val=3x3, do_normalise=True) (Quaternion.py:45-46,69): Markley's method on M as
+// given -- NO orthogonalisation (scipy 1.10.1, the reference's pin) -- then unit, w >= 0.
+template <typename T>
+__device__ __forceinline__ void mat_to_quat(const T* M, T* q) {
+    const T tr = M[0] + M[4] + M[8];
+    // first maximum of (M00, M11, M22, tr), like numpy.argmax
+    int c = 0;
+    T best = M[0];
+    if (M[4] > best) { best = M[4]; c = 1; }
+    if (M[8] > best) { best = M[8]; c = 2; }
+    if (tr > best) { c = 3; }
+    if (c == 3) {
+        q[0] = M[7] - M[5]; q[1] = M[2] - M[6]; q[2] = M[3] - M[1]; q[3] = T(1) + tr;
+    } else if (c == 0) {
+        q[0] = T(1) - tr + T(2) * M[0]; q[1] = M[3] + M[1]; q[2] = M[6] + M[2]; q[3] = M[7] - M[5];
+    } else if (c == 1) {
+        q[1] = T(1) - tr + T(2) * M[4]; q[2] = M[7] + M[5]; q[0] = M[1] + M[3]; q[3] = M[2] - M[6];
+    } else {
+        q[2] = T(1) - tr + T(2) * M[8]; q[0] = M[2] + M[6]; q[1] = M[5] + M[7]; q[3] = M[3] - M[1];
+    }
+    quat_nrm(q);
+}
+// Quaternion.about_axis (Quaternion.py:209-224)
+template <typename T>
+__device__ __forceinline__ void quat_about_axis(T angle, const T* axis, T* q) {
+    const T len = t_sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    T s, c;
+    t_sincos(T(0.5) * angle, s, c);
+    // guard constant is 4*eps of float64 in the reference, whatever the working precision
+    const T f = (len > T(8.881784197001252e-16)) ? s / len : T(1);
+    q[0] = axis[0] * f; q[1] = axis[1] * f; q[2] = axis[2] * f; q[3] = c;
+    quat_nrm(q);
+}
+
+// ----------------------------------------------------------------------------------
+// probe kinematics in closed form (models/Probe.py:147-167)
+// ----------------------------------------------------------------------------------
+template <typename T>
+struct ProbeTrig {
+    T s1, c1, s2, c2, s3, c3, sp, cp;   // sin/cos of q1, q2, q3, phi = q3 - q7
+};
+template <typename T>
+__device__ __forceinline__ ProbeTrig<T> probe_trig(const T* dofs, T q7) {
+    ProbeTrig<T> t;
+    t_sincos(dofs[0], t.s1, t.c1);
+    t_sincos(dofs[1], t.s2, t.c2);
+    t_sincos(dofs[2], t.s3, t.c3);
+    t_sincos(dofs[2] - q7, t.sp, t.cp);
+    return t;
+}
+#define E5(s, c, o)   { o[0] = t.s1 * t.s2 * (s) - t.c1 * (c); o[1] = t.s1 * (c) + t.c1 * t.s2 * (s); o[2] = t.c2 * (s); }
+#define E6(s, c, o)   { o[0] = t.s1 * t.s2 * (c) + t.c1 * (s); o[1] = t.c1 * t.s2 * (c) - t.s1 * (s); o[2] = t.c2 * (c); }
+#define E5_1(s, c, o) { o[0] = t.c1 * t.s2 * (s) + t.s1 * (c); o[1] = t.c1 * (c) - t.s1 * t.s2 * (s); o[2] = T(0); }
+#define E6_1(s, c, o) { o[0] = t.c1 * t.s2 * (c) - t.s1 * (s); o[1] = -t.s1 * t.s2 * (c) - t.c1 * (s); o[2] = T(0); }
+#define E5_2(s, c, o) { o[0] = t.s1 * t.c2 * (s); o[1] = t.c1 * t.c2 * (s); o[2] = -t.s2 * (s); }
+#define E6_2(s, c, o) { o[0] = t.s1 * t.c2 * (c); o[1] = t.c1 * t.c2 * (c); o[2] = -t.s2 * (c); }
+
+// p_CB, R_BC, z6 -- the outputs of SymProbe.get_est_fwkin that are not identically zero
+template <typename T>
+__device__ __forceinline__ void probe_pose(const ProbeTrig<T>& t, const T* dofs, T L, T st, T ct, T* p, T* R, T* z6) {
+    T e5[3], e6[3], a[3], g[3];
+    z6[0] = -t.s1 * t.c2; z6[1] = -t.c1 * t.c2; z6[2] = t.s2;
+    E5(t.s3, t.c3, e5); E6(t.s3, t.c3, e6);
+    E5(t.sp, t.cp, a);  E6(t.sp, t.cp, g);
+    const T lq = L - dofs[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        p[i] = lq * z6[i] + dofs[4] * e5[i] + dofs[5] * e6[i];
+        R[3 * i + 0] = -a[i];
+        R[3 * i + 1] = ct * g[i] + st * z6[i];
+        R[3 * i + 2] = -st * g[i] + ct * z6[i];
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// per-instance register state
+// ----------------------------------------------------------------------------------
+template <typename T>
+struct State {
+    T p[3], v[3], q[4], dofs[6], notch[3], pc[3], qc[4];   // x26 (state.py:11-29)
+    T om_o[3], acc_o[3], qo[4];                            // Filter.py:78-80 buffers
+};
+
+// Blocks of the error-state transition Fx that are not structural constants
+// (SURVEY.md App. A.3).  Row 18+r: dt at col 3+r | Bm[r][:] at 6:9 | Cm[r][:] at 9:15 | 1 at col
+// 16+r.  Row 21+r: Dm[r][0:3] at 9:12 | Dm[r][3] at col 15 | Em[r][:] at 19:22 | 1 at (22,22),(23,23).
+template <typename T>
+struct Jac {
+    T A[9];     // Fx[3:6,6:9]  = -dt R_o [a_o]x            (Filter.py:254)
+    T Th[9];    // Fx[6:9,6:9]  = Rm(Om_old)^T              (Filter.py:255,132-134)
+    T Bm[9], Cm[18], Dm[12], Em[9];
+    T N6[18];   // Fi[18:24,3:6] (6x3): dt R_o [p]x ; -dt R_BC^T
+    T dt;
+};
+
+// Filter._predict_nominal (Filter.py:232-247) + eqns.f_predict (equations.py:44-50,72-100)
+// + State.from_array (state.py:62-74), then the Jacobian blocks of Filter._predict_error /
+// _cam_error_jacobian (Filter.py:249-342) evaluated -- as the reference does -- at the
+// post-step dofs/notch with the pre-step buffers om_old, acc_old, R_WB_old.
+template <typename T>
+__device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& prm, T dt, const T* om_n,
+                                               const T* acc_n, Jac<T>& J) {
+    T R[9], Rc[9], Ro[9];
+    quat_to_mat(s.q, R);
+    quat_to_mat(s.qc, Rc);
+    quat_to_mat(s.qo, Ro);
+
+    // --- nominal state -------------------------------------------------------------
+    {
+        const ProbeTrig<T> t = probe_trig(s.dofs, s.notch[0]);
+        T pB[3], RBC[9], z6[3];
+        probe_pose(t, s.dofs, prm.L, prm.st, prm.ct, pB, RBC, z6);
+
+        T om_avg[3], w[3], RS[9], Rn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { om_avg[i] = (s.om_o[i] + om_n[i]) * T(0.5); w[i] = dt * om_avg[i]; }
+        mat3_skew(R, w, RS);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rn[i] = R[i] + RS[i];                           // equations.py:46
+        T a1[3], a2[3], acc_avg[3];
+        mat3_vec(R, s.acc_o, a1);
+        mat3_vec(Rn, acc_n, a2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);          // equations.py:47
+        T u[3], C_om[3], cr[3], Rcr[3], wc[3], RcS[9], Rcn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = s.om_o[i] + z6[i] * s.notch[1];
+        mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
+        cross3(om_avg, pB, cr);                                                     // BB_v_CB == 0
+        mat3_vec(R, cr, Rcr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T vi = s.v[i];
+            s.p[i] = s.p[i] + dt * vi + (dt * dt * T(0.5)) * acc_avg[i];            // equations.py:76
+            s.v[i] = vi + dt * acc_avg[i];                                          // equations.py:77
+            s.pc[i] = s.pc[i] + dt * vi + dt * Rcr[i];                              // equations.py:83-85
+            wc[i] = dt * C_om[i];
+        }
+        mat3_skew(Rc, wc, RcS);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rcn[i] = Rc[i] + RcS[i];                        // equations.py:86
+        s.notch[0] += dt * s.notch[1];                                              // equations.py:80-82
+        s.notch[1] += dt * s.notch[2];
+        if (!prm.hold_frozen) {                                                     // Filter.py:243-245
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if ((prm.frozen_mask >> i) & 1) s.dofs[i] = T(0);
+        }
+        mat_to_quat(Rn, s.q);                                                       // state.py:67
+        mat_to_quat(Rcn, s.qc);                                                     // state.py:72
+    }
+
+    // --- Jacobian blocks -----------------------------------------------------------
+    J.dt = dt;
+    {
+        T w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = -dt * s.acc_o[i];
+        mat3_skew(Ro, w, J.A);                                                      // -dt R_o [a_o]x
+        T Om[4] = {T(0.5) * dt * s.om_o[0], T(0.5) * dt * s.om_o[1], T(0.5) * dt * s.om_o[2], T(1)};
+        T OmR[9];
+        quat_to_mat(Om, OmR);                                                       // Filter.py:132-134
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J.Th[3 * i + j] = OmR[3 * j + i];
+    }
+    {
+        const ProbeTrig<T> t = probe_trig(s.dofs, s.notch[0]);
+        const T st = prm.st, ct = prm.ct;
+        T z6[3], z6_1[3], z6_2[3], e5[3], e6[3], e5_1[3], e5_2[3], e6_1[3], e6_2[3];
+        T a[3], g[3], a_1[3], a_2[3], g_1[3], g_2[3];
+        z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
+        z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
+        z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
+        E5(t.s3, t.c3, e5);     E6(t.s3, t.c3, e6);
+        E5_1(t.s3, t.c3, e5_1); E6_1(t.s3, t.c3, e6_1);
+        E5_2(t.s3, t.c3, e5_2); E6_2(t.s3, t.c3, e6_2);
+        E5(t.sp, t.cp, a);      E6(t.sp, t.cp, g);
+        E5_1(t.sp, t.cp, a_1);  E6_1(t.sp, t.cp, g_1);
+        E5_2(t.sp, t.cp, a_2);  E6_2(t.sp, t.cp, g_2);
+
+        const T lq = prm.L - s.dofs[3], q5 = s.dofs[4], q6 = s.dofs[5], thd = s.notch[1];
+        T p[3], Jp[18];   // Jp[3][6]: d p_CB / d q1..q6 (the q7 column is identically zero)
+        T RBC[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            p[i] = lq * z6[i] + q5 * e5[i] + q6 * e6[i];
+            Jp[6 * i + 0] = lq * z6_1[i] + q5 * e5_1[i] + q6 * e6_1[i];
+            Jp[6 * i + 1] = lq * z6_2[i] + q5 * e5_2[i] + q6 * e6_2[i];
+            Jp[6 * i + 2] = q5 * e6[i] - q6 * e5[i];
+            Jp[6 * i + 3] = -z6[i];
+            Jp[6 * i + 4] = e5[i];
+            Jp[6 * i + 5] = e6[i];
+            RBC[3 * i + 0] = -a[i];
+            RBC[3 * i + 1] = ct * g[i] + st * z6[i];
+            RBC[3 * i + 2] = -st * g[i] + ct * z6[i];
+        }
+        // noise symbols are evaluated at their std-devs (Filter.py:330-333); "true" v_CB := p_CB
+        // (Probe.py:458)
+        T om_t[3], wv[3], cr[3], u_t[3], u_o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) om_t[i] = s.om_o[i] - prm.sig_om[i];
+        cross3(om_t, p, cr);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            wv[i] = -dt * (p[i] + cr[i]);
+            u_t[i] = om_t[i] + z6[i] * thd;
+            u_o[i] = s.om_o[i] + z6[i] * thd;
+        }
+        mat3_skew(Ro, wv, J.Bm);                                                    // -dt R_o [p + om_t x p]x
+        // M = dt R_o (I + [om_t]x);  Cm = M Jp
+        T RoS[9], M[9];
+        mat3_skew(Ro, om_t, RoS);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) M[i] = dt * (Ro[i] + RoS[i]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                J.Cm[6 * r + c] = M[3 * r] * Jp[c] + M[3 * r + 1] * Jp[6 + c] + M[3 * r + 2] * Jp[12 + c];
+        // delta-theta_C rows: d/dq_i [ R_BC^T (om_t + z6 thd) ] with only R_BC and z6 depending on q
+        // columns of dR_BC/dq_i are (-da, ct dg + st dz, -st dg + ct dz)
+        auto dcol = [&](const T* da, const T* dg, const T* dz, const T* dzr, int col) {
+            T d0 = T(0), d1 = T(0), d2 = T(0);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d0 += -da[k] * u_t[k];
+                d1 += (ct * dg[k] + st * dz[k]) * u_t[k];
+                d2 += (-st * dg[k] + ct * dz[k]) * u_t[k];
+            }
+            T rz[3];
+            mat3T_vec(RBC, dzr, rz);
+            J.Dm[0 * 4 + col] = dt * (d0 + rz[0] * thd);
+            J.Dm[1 * 4 + col] = dt * (d1 + rz[1] * thd);
+            J.Dm[2 * 4 + col] = dt * (d2 + rz[2] * thd);
+        };
+        const T zero3[3] = {T(0), T(0), T(0)};
+        T ma[3] = {-a[0], -a[1], -a[2]}, mg[3] = {-g[0], -g[1], -g[2]};
+        dcol(a_1, g_1, z6_1, z6_1, 0);      // q1
+        dcol(a_2, g_2, z6_2, z6_2, 1);      // q2
+        dcol(g, ma, zero3, zero3, 2);       // q3:  da/dphi = g, dg/dphi = -a
+        dcol(mg, a, zero3, zero3, 3);       // q7:  phi = q3 - q7
+        T ac[3], bc[3], hs[3];
+        mat3T_vec(RBC, u_t, ac);
+        mat3T_vec(RBC, u_o, bc);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) hs[i] = T(0.5) * dt * (ac[i] + bc[i]);
+        // Em = I - [hs]x
+        J.Em[0] = T(1);   J.Em[1] = hs[2];  J.Em[2] = -hs[1];
+        J.Em[3] = -hs[2]; J.Em[4] = T(1);   J.Em[5] = hs[0];
+        J.Em[6] = hs[1];  J.Em[7] = -hs[0]; J.Em[8] = T(1);
+        // noise Jacobian camera rows (only needed when the gyro block of Q is non-zero)
+        T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
+        mat3_skew(Ro, dp, J.N6);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
+    }
+    // buffer swap (Filter.py:225-227)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s.om_o[i] = om_n[i]; s.acc_o[i] = acc_n[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+}
+
+// ----------------------------------------------------------------------------------
+// LDS region of one instance (units of T)
+// ----------------------------------------------------------------------------------
+constexpr int PS = 25;             // row stride of P
+constexpr int OFF_P = 0;           // 24 x 25
+constexpr int OFF_S = 600;         // scratch: U 6x24 (predict) | Z 24x7 (update)
+constexpr int OFF_X = 768;         // 36 state words (+4 pad)
+constexpr int OFF_E = 808;         // 24 error-state words
+constexpr int REGION_MIN = 832;
+// regions of the instances sharing a wave are staggered so that their windows fall on
+// different banks: REGION = LPI (mod 32) (conflict-free for the 8-byte accesses below)
+__host__ __device__ constexpr int region_words(int lpi) {
+    int r = REGION_MIN;
+    while ((r % 32) != (lpi % 32)) ++r;
+    return r;
+}
+
+__device__ __forceinline__ void group_sync() { __syncthreads(); }   // block == one wavefront
+
+// packed index -> (i, j), i >= j
+__device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
+    const int r = e / 25, c = e - 25 * r;
+    if (c <= r) { i = r; j = c; } else { i = 23 - r; j = c - r - 1; }
+}
+
+template <typename T, int LPI>
+__global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
+    constexpr int G = 64 / LPI;
+    constexpr int REGION = region_words(LPI);
+    __shared__ T smem[G * REGION];
+
+    const int lane = threadIdx.x;
+    const int grp = lane / LPI;
+    const int lig = lane - grp * LPI;
+    const int64_t inst = (int64_t)blockIdx.x * G + grp;
+    if (grp >= G || inst >= a.B) return;   // idle lanes / tail instances: whole group leaves together
+
+    T* sP = smem + grp * REGION + OFF_P;
+    T* sS = smem + grp * REGION + OFF_S;
+    T* sX = smem + grp * REGION + OFF_X;
+    T* sE = smem + grp * REGION + OFF_E;
+
+    T* gP = reinterpret_cast<T*>(a.P) + inst * 300;
+    T* gX = reinterpret_cast<T*>(a.xs) + inst * 36;
+
+    // ---- load: packed P -> full symmetric LDS image, state words -> LDS --------------
+    for (int e = lig; e < 300; e += LPI) {
+        int i, j;
+        unpack_ij(e, i, j);
+        const T v = gP[e];
+        sP[i * PS + j] = v;
+        sP[j * PS + i] = v;
+    }
+    for (int e = lig; e < 36; e += LPI) sX[e] = gX[e];
+    group_sync();
+
+    State<T> s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { s.p[i] = sX[i]; s.v[i] = sX[3 + i]; s.notch[i] = sX[16 + i]; s.pc[i] = sX[19 + i];
+                                  s.om_o[i] = sX[26 + i]; s.acc_o[i] = sX[29 + i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s.q[i] = sX[6 + i]; s.qc[i] = sX[22 + i]; s.qo[i] = sX[32 + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s.dofs[i] = sX[10 + i];
+
+    // ================================ predict(s) =======================================
+    for (int ip = 0; ip < a.n_pred; ++ip) {
+        T dt, om_n[3], acc_n[3];
+        {
+            const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + inst : ip);
+            const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + inst) * 3 : (int64_t)ip * 3;
+            const T* gom = reinterpret_cast<const T*>(a.om) + so;
+            const T* gac = reinterpret_cast<const T*>(a.acc) + so;
+            dt = gdt[0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { om_n[i] = gom[i]; acc_n[i] = gac[i]; }
+        }
+        Jac<T> J;
+        predict_scalar(s, prm, dt, om_n, acc_n, J);
+
+        // ---- phase 1: lane owns column j.  U[:,j] = Fx[18:24,:] P[:,j]; then the row
+        // operations of Faa = Fx[0:18,0:18] on column j (rows 0:9, 15, 16), all from the
+        // old column held in registers -> no intra-phase hazard.
+        for (int j = lig; j < 24; j += LPI) {
+            T c[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) c[k] = sP[k * PS + j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                T u = dt * c[3 + r] + c[16 + r];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) u += J.Bm[3 * r + k] * c[6 + k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u += J.Cm[6 * r + k] * c[9 + k];
+                sS[r * 24 + j] = u;
+                T w = J.Dm[4 * r + 3] * c[15];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w += J.Dm[4 * r + k] * c[9 + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w += J.Em[3 * r + k] * c[19 + k];
+                if (r == 1) w += c[22];
+                if (r == 2) w += c[23];
+                sS[(3 + r) * 24 + j] = w;
+            }
+            if (j < 18) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    sP[r * PS + j] = c[r] + dt * c[3 + r];
+                    sP[(3 + r) * PS + j] = c[3 + r] + J.A[3 * r] * c[6] + J.A[3 * r + 1] * c[7] + J.A[3 * r + 2] * c[8];
+                    sP[(6 + r) * PS + j] = J.Th[3 * r] * c[6] + J.Th[3 * r + 1] * c[7] + J.Th[3 * r + 2] * c[8];
+                }
+                sP[15 * PS + j] = c[15] + dt * c[16];
+                sP[16 * PS + j] = c[16] + dt * c[17];
+            }
+        }
+        group_sync();
+
+        // ---- phase 2: lane owns a row.  Rows 0..17: column operations of Faa^T plus the
+        // diagonal of Fi Q Fi^T.  Rows 18..23 (owner of U row a): P'cc = U Fc^T, P'ca = U
+        // Faa^T, camera part of Fi Q Fi^T; written to row 18+a and mirrored into column 18+a.
+        for (int it = lig; it < 24; it += LPI) {
+            if (it < 18) {
+                const int i = it;
+                T c[9], c15, c16, c17;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) c[k] = sP[i * PS + k];
+                c15 = sP[i * PS + 15]; c16 = sP[i * PS + 16]; c17 = sP[i * PS + 17];
+                T n[9];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    n[r] = c[r] + dt * c[3 + r];
+                    n[3 + r] = c[3 + r] + J.A[3 * r] * c[6] + J.A[3 * r + 1] * c[7] + J.A[3 * r + 2] * c[8];
+                    n[6 + r] = J.Th[3 * r] * c[6] + J.Th[3 * r + 1] * c[7] + J.Th[3 * r + 2] * c[8];
+                }
+                const T n15 = c15 + dt * c16, n16 = c16 + dt * c17;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sP[i * PS + k] = n[k];
+                sP[i * PS + 15] = n15; sP[i * PS + 16] = n16;
+                // Fi Q Fi^T diagonal: rows 3..14 <- Q[i-3], row 17 <- Q[12]  (Filter.py:263-264,349)
+                // (select chain: a runtime index into the by-value parameter block would spill it)
+                {
+                    T qi = T(0);
+#pragma unroll
+                    for (int k = 0; k < 12; ++k) qi = (i == 3 + k) ? prm.qd[k] : qi;
+                    qi = (i == 17) ? prm.qd[12] : qi;
+                    if (i >= 3) sP[i * PS + i] += qi;
+                }
+            } else {
+                const int ar = it - 18;
+                T u[24];
+#pragma unroll
+                for (int k = 0; k < 24; ++k) u[k] = sS[ar * 24 + k];
+                T row[24];
+                // P'cc[ar][b]
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    T x = dt * u[3 + b] + u[16 + b];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) x += J.Bm[3 * b + k] * u[6 + k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) x += J.Cm[6 * b + k] * u[9 + k];
+                    row[18 + b] = x;
+                    T y = J.Dm[4 * b + 3] * u[15];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) y += J.Dm[4 * b + k] * u[9 + k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) y += J.Em[3 * b + k] * u[19 + k];
+                    if (b == 1) y += u[22];
+                    if (b == 2) y += u[23];
+                    row[21 + b] = y;
+                }
+                // P'ca[ar][0:18] = U[ar][0:18] Faa^T
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    row[r] = u[r] + dt * u[3 + r];
+                    row[3 + r] = u[3 + r] + J.A[3 * r] * u[6] + J.A[3 * r + 1] * u[7] + J.A[3 * r + 2] * u[8];
+                    row[6 + r] = J.Th[3 * r] * u[6] + J.Th[3 * r + 1] * u[7] + J.Th[3 * r + 2] * u[8];
+                }
+#pragma unroll
+                for (int k = 9; k < 15; ++k) row[k] = u[k];
+                row[15] = u[15] + dt * u[16];
+                row[16] = u[16] + dt * u[17];
+                row[17] = u[17];
+                if (prm.q_gyro) {   // Fi[6:9,3:6] = I couples the gyro noise into the camera rows
+                    T nr[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        // N6[ar][k] with a runtime row index: select
+                        T v = J.N6[k];
+#pragma unroll
+                        for (int rr = 1; rr < 6; ++rr) v = (ar == rr) ? J.N6[3 * rr + k] : v;
+                        nr[k] = v * prm.qd[3 + k];
+                        row[6 + k] += nr[k];
+                    }
+#pragma unroll
+                    for (int b = 0; b < 6; ++b)
+                        row[18 + b] += nr[0] * J.N6[3 * b] + nr[1] * J.N6[3 * b + 1] + nr[2] * J.N6[3 * b + 2];
+                }
+#pragma unroll
+                for (int k = 0; k < 24; ++k) sP[(18 + ar) * PS + k] = row[k];
+#pragma unroll
+                for (int k = 0; k < 18; ++k) sP[k * PS + 18 + ar] = row[k];
+            }
+        }
+        group_sync();
+    }
+
+    // ================================ update ===========================================
+    int status = 0;
+    if (a.do_update) {
+        // ---- scalar: S = H P H^T + R (H selects rows 18..23,15: Filter.py:83-85), LDL^T ----
+        constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
+        T Lm[21], d[7], rd[7];   // unit-lower L packed by rows: L[i][j] at i(i-1)/2 + j
+        bool ok = true;
+        {
+            T S[28];
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) S[i * (i + 1) / 2 + j] = sP[sel[i] * PS + sel[j]] + (i == j ? prm.r[i] : T(0));
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                T dj = S[j * (j + 1) / 2 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj -= Lm[j * (j - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
+                d[j] = dj;
+                ok = ok && (dj != T(0)) && t_finite(dj);
+                rd[j] = T(1) / dj;
+#pragma unroll
+                for (int i = j + 1; i < 7; ++i) {
+                    T v = S[i * (i + 1) / 2 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= Lm[i * (i - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
+                    Lm[i * (i - 1) / 2 + j] = v * rd[j];
+                }
+            }
+        }
+        if (!ok) status |= DVI_STATUS_SINGULAR;
+
+        // ---- scalar: measurement correction and residual (Filter.py:364-375) ---------------
+        T res[7];
+        {
+            const int64_t mo = a.meas_stride ? inst : 0;
+            const T* gpos = reinterpret_cast<const T*>(a.pos) + mo * 3;
+            const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
+            const T ang_notch = reinterpret_cast<const T*>(a.notch)[mo];
+            T qraw[4] = {gq[0], gq[1], gq[2], gq[3]};
+            T nq[4] = {T(0), T(0), T(0), T(1)};
+            t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
+            T qm[4], qe[4];
+            quat_mul(nq, qraw, qm);
+            quat_nrm(qm);
+            qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
+            quat_mul(qm, s.qc, qe);
+            quat_nrm(qe);
+            T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
+            if (nv > T(1)) { nv = T(1); status |= DVI_STATUS_NONFINITE; }
+            const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+            const T f = (nv == T(0)) ? T(0) : ang / nv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { res[i] = gpos[i] - s.pc[i]; res[3 + i] = f * qe[i]; }
+            res[6] = ang_notch - s.notch[0];
+        }
+
+        // ---- phase 3: lane owns row i: Z[i,:] L^T = P[i,sel]; K[i,:] = (Z D^-1) L^-1; e_i = K[i,:] res
+        if (ok) {
+            for (int i = lig; i < 24; i += LPI) {
+                T z[7], k[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) {
+                    T v = sP[i * PS + sel[m]];
+#pragma unroll
+                    for (int n = 0; n < m; ++n) v -= z[n] * Lm[m * (m - 1) / 2 + n];
+                    z[m] = v;
+                }
+#pragma unroll
+                for (int m = 6; m >= 0; --m) {
+                    T v = z[m] * rd[m];
+#pragma unroll
+                    for (int n = m + 1; n < 7; ++n) v -= k[n] * Lm[n * (n - 1) / 2 + m];
+                    k[m] = v;
+                }
+                T e = T(0);
+#pragma unroll
+                for (int m = 0; m < 7; ++m) { e += k[m] * res[m]; sS[i * 7 + m] = z[m]; }
+                if (i >= 9 && i < 15 && ((prm.frozen_mask >> (i - 9)) & 1)) e = T(0);   // Filter.py:377-379
+                sE[i] = e;
+                if (a.K_out) {
+                    T* gK = reinterpret_cast<T*>(a.K_out) + (inst * 24 + i) * 7;
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) gK[m] = k[m];
+                }
+            }
+        }
+        group_sync();
+
+        T Gt[3], Gc[3];   // half error angles for the reset Jacobian
+        if (ok) {
+            // ---- scalar: ErrorState.from_array (state.py:105-129) + State.__add__ (46-60)
+            T e[24];
+#pragma unroll
+            for (int i = 0; i < 24; ++i) e[i] = sE[i];
+            const T* th = e + 6;
+            const T* thc = e + 21;
+            T dq[4], dqc[4], qn[4], qcn[4];
+            quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
+            quat_about_axis(t_sqrt(thc[0] * thc[0] + thc[1] * thc[1] + thc[2] * thc[2]), th, dqc);   // sic (state.py:124)
+            quat_mul(s.q, dq, qn);
+            quat_nrm(qn);
+            quat_mul(s.qc, dqc, qcn);
+            quat_nrm(qcn);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                s.p[i] += e[i]; s.v[i] += e[3 + i]; s.notch[i] += e[15 + i]; s.pc[i] += e[18 + i];
+                Gt[i] = T(0.5) * th[i]; Gc[i] = T(0.5) * thc[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s.dofs[i] += e[9 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s.q[i] = qn[i]; s.qc[i] = qcn[i]; }
+
+            // ---- phase 4: lane owns column j.  P[:,j] -= Z (D^-1 Z[j,:]^T)  (Joseph form with the
+            // optimal gain, Filter.py:383-384), then the row part of the reset G P G^T
+            // (Filter.py:387-390) on its own column.
+            for (int j = lig; j < 24; j += LPI) {
+                T zd[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) zd[m] = sS[j * 7 + m] * rd[m];
+                T c[24];
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    T v = sP[i * PS + j];
+#pragma unroll
+                    for (int m = 0; m < 7; ++m) v -= sS[i * 7 + m] * zd[m];
+                    c[i] = v;
+                }
+                // rows 6:9 <- (I - [Gt]x) rows 6:9 ; rows 21:24 <- (I - [Gc]x) rows 21:24
+                {
+                    const T a0 = c[6], a1 = c[7], a2 = c[8];
+                    c[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
+                    c[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
+                    c[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
+                    const T b0 = c[21], b1 = c[22], b2 = c[23];
+                    c[21] = b0 + Gc[2] * b1 - Gc[1] * b2;
+                    c[22] = b1 - Gc[2] * b0 + Gc[0] * b2;
+                    c[23] = b2 + Gc[1] * b0 - Gc[0] * b1;
+                }
+#pragma unroll
+                for (int i = 0; i < 24; ++i) sP[i * PS + j] = c[i];
+            }
+        }
+        group_sync();
+        if (ok) {
+            // ---- phase 5: lane owns row i: column part of the reset.
+            for (int i = lig; i < 24; i += LPI) {
+                const T a0 = sP[i * PS + 6], a1 = sP[i * PS + 7], a2 = sP[i * PS + 8];
+                sP[i * PS + 6] = a0 + Gt[2] * a1 - Gt[1] * a2;
+                sP[i * PS + 7] = a1 - Gt[2] * a0 + Gt[0] * a2;
+                sP[i * PS + 8] = a2 + Gt[1] * a0 - Gt[0] * a1;
+                const T b0 = sP[i * PS + 21], b1 = sP[i * PS + 22], b2 = sP[i * PS + 23];
+                sP[i * PS + 21] = b0 + Gc[2] * b1 - Gc[1] * b2;
+                sP[i * PS + 22] = b1 - Gc[2] * b0 + Gc[0] * b2;
+                sP[i * PS + 23] = b2 + Gc[1] * b0 - Gc[0] * b1;
+            }
+        }
+        group_sync();
+        if (a.status && lig == 0) a.status[inst] = status;
+    }
+
+    // ---- store ---------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { sX[i] = s.p[i]; sX[3 + i] = s.v[i]; sX[16 + i] = s.notch[i]; sX[19 + i] = s.pc[i];
+                                  sX[26 + i] = s.om_o[i]; sX[29 + i] = s.acc_o[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sX[6 + i] = s.q[i]; sX[22 + i] = s.qc[i]; sX[32 + i] = s.qo[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) sX[10 + i] = s.dofs[i];
+    group_sync();
+    for (int e = lig; e < 36; e += LPI) gX[e] = sX[e];
+    for (int e = lig; e < 300; e += LPI) {
+        int i, j;
+        unpack_ij(e, i, j);
+        gP[e] = sP[i * PS + j];
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// state import / export between the user-facing layout and the device records
+// ----------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_state_kernel(int64_t B, const T* x26, const T* P576, const T* om3, const T* acc3, const T* qo4,
+                                  T* xs, T* Ppk) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (P576) {
+        for (int64_t t = tid; t < B * 300; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = t / 300;
+            int i, j;
+            unpack_ij((int)(t - b * 300), i, j);
+            Ppk[t] = P576[b * 576 + i * 24 + j];
+        }
+    }
+    for (int64_t t = tid; t < B * 36; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / 36;
+        const int w = (int)(t - b * 36);
+        if (w < 26) { if (x26) xs[t] = x26[b * 26 + w]; }
+        else if (w < 29) { if (om3) xs[t] = om3[b * 3 + (w - 26)]; }
+        else if (w < 32) { if (acc3) xs[t] = acc3[b * 3 + (w - 29)]; }
+        else {
+            if (qo4) xs[t] = qo4[b * 4 + (w - 32)];
+            else if (x26) xs[t] = x26[b * 26 + 6 + (w - 32)];     // R_WB_old = Rm(q) (Filter.py:80)
+        }
+    }
+}
+
+template <typename T>
+__global__ void unpack_state_kernel(int64_t B, const T* xs, const T* Ppk, T* x26, T* P576, T* om3, T* acc3, T* qo4,
+                                    T* dofs6) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (P576) {
+        for (int64_t t = tid; t < B * 300; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t b = t / 300;
+            int i, j;
+            unpack_ij((int)(t - b * 300), i, j);
+            const T v = Ppk[t];
+            P576[b * 576 + i * 24 + j] = v;
+            P576[b * 576 + j * 24 + i] = v;
+        }
+    }
+    for (int64_t t = tid; t < B * 36; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / 36;
+        const int w = (int)(t - b * 36);
+        const T v = xs[t];
+        if (w < 26) { if (x26) x26[b * 26 + w] = v; if (dofs6 && w >= 10 && w < 16) dofs6[b * 6 + (w - 10)] = v; }
+        else if (w < 29) { if (om3) om3[b * 3 + (w - 26)] = v; }
+        else if (w < 32) { if (acc3) acc3[b * 3 + (w - 29)] = v; }
+        else { if (qo4) qo4[b * 4 + (w - 32)] = v; }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// host-side launchers
+// ----------------------------------------------------------------------------------
+template <typename T, int LPI>
+static hipError_t launch_step_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+    constexpr int G = 64 / LPI;
+    const int64_t blocks = (a.B + G - 1) / G;
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((eskf_step_kernel<T, LPI>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_step_lpi(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+    switch (lpi) {
+        case 64: return launch_step_t<T, 64>(a, prm, stream);
+        case 32: return launch_step_t<T, 32>(a, prm, stream);
+        case 16: return launch_step_t<T, 16>(a, prm, stream);
+        case 12: return launch_step_t<T, 12>(a, prm, stream);
+        case 8:  return launch_step_t<T, 8>(a, prm, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
+    if (dtype == 0) return launch_step_lpi<double>(lpi, a, make_dev_params<double>(hp), stream);
+    return launch_step_lpi<float>(lpi, a, make_dev_params<float>(hp), stream);
+}
+
+hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
+                       const void* qo4, void* xs, void* Ppk, hipStream_t stream) {
+    const int threads = 256;
+    const int64_t work = B * 300;
+    const unsigned blocks = (unsigned)((work + threads - 1) / threads > 65535 ? 65535 : (work + threads - 1) / threads);
+    if (dtype == 0)
+        hipLaunchKernelGGL(pack_state_kernel<double>, dim3(blocks), dim3(threads), 0, stream, B, (const double*)x26,
+                           (const double*)P576, (const double*)om3, (const double*)acc3, (const double*)qo4, (double*)xs,
+                           (double*)Ppk);
+    else
+        hipLaunchKernelGGL(pack_state_kernel<float>, dim3(blocks), dim3(threads), 0, stream, B, (const float*)x26,
+                           (const float*)P576, (const float*)om3, (const float*)acc3, (const float*)qo4, (float*)xs,
+                           (float*)Ppk);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,
+                         void* acc3, void* qo4, void* dofs6, hipStream_t stream) {
+    const int threads = 256;
+    const int64_t work = B * 300;
+    const unsigned blocks = (unsigned)((work + threads - 1) / threads > 65535 ? 65535 : (work + threads - 1) / threads);
+    if (dtype == 0)
+        hipLaunchKernelGGL(unpack_state_kernel<double>, dim3(blocks), dim3(threads), 0, stream, B, (const double*)xs,
+                           (const double*)Ppk, (double*)x26, (double*)P576, (double*)om3, (double*)acc3, (double*)qo4,
+                           (double*)dofs6);
+    else
+        hipLaunchKernelGGL(unpack_state_kernel<float>, dim3(blocks), dim3(threads), 0, stream, B, (const float*)xs,
+                           (const float*)Ppk, (float*)x26, (float*)P576, (float*)om3, (float*)acc3, (float*)qo4,
+                           (float*)dofs6);
+    return hipGetLastError();
+}
+
+}  // namespace eskf

@@ -1,0 +1,136 @@
+/* dvi_eskf.h -- C ABI of the MI355X batched error-state Kalman filter.
+ *
+ * The reference (salehahr/dvi-ekf @ v1) is a pure-Python package with no FFI; the
+ * boundary this library sits behind is the Python class `Filter`
+ * (dvi_ekf/filter/Filter.py:28-476).  Each entry point below names the reference
+ * method(s) it replaces.  Python binding: dvi_ekf_amd/_capi.py (ctypes); see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative DVI_ESKF_E* code; nothing
+ *    throws across the ABI; dvi_eskf_strerror() explains a code.
+ *  - all array arguments are HIP *device* pointers (e.g. torch tensor.data_ptr())
+ *    of the handle's dtype, C-contiguous, batch-major; `stream` is a hipStream_t
+ *    (NULL = default stream).  Work is enqueued asynchronously on that stream.
+ *    Small constants (params, Q, R) are host pointers.
+ *  - the library never frees caller buffers; one handle is not thread-safe,
+ *    distinct handles are independent.
+ *  - state vector x26 = p(3) v(3) q(xyzw 4) dofs(6) notch(3) p_cam(3) q_cam(xyzw 4)
+ *    (dvi_ekf/filter/state.py:11-86); error state = 24 (state.py:89-129).
+ */
+#ifndef DVI_ESKF_H
+#define DVI_ESKF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVI_ESKF_NX 26
+#define DVI_ESKF_NE 24
+#define DVI_ESKF_NN 13
+#define DVI_ESKF_NM 7
+
+#define DVI_ESKF_F64 0
+#define DVI_ESKF_F32 1
+
+#define DVI_ESKF_OK 0
+#define DVI_ESKF_EINVAL (-1)    /* bad argument (null handle, bad dtype, non-diagonal Q/R, ...) */
+#define DVI_ESKF_ENODEV (-2)    /* no usable HIP device                                         */
+#define DVI_ESKF_ENOMEM (-3)    /* device allocation failed                                     */
+#define DVI_ESKF_EHIP (-4)      /* a HIP runtime call / kernel launch failed                    */
+
+/* per-instance status word written by update / step */
+#define DVI_ESKF_STATUS_SINGULAR 1  /* innovation covariance not factorisable: state and P left
+                                       untouched -- the `return None` path of Filter.py:356-361 */
+#define DVI_ESKF_STATUS_NONFINITE 2 /* asin argument clamped or non-finite value seen           */
+
+typedef struct dvi_eskf dvi_eskf;
+
+/* Constants that Filter.__init__ takes from the config / Simulator (Filter.py:34-93). */
+typedef struct {
+    double L;             /* probe length, config.yaml:33 (model.length)                   */
+    double theta_cam;     /* camera angle [rad], config.yaml:34 / config.py:131-133        */
+    int32_t frozen[6];    /* frozen-DOF mask, config.yaml:8; Filter.py:56,243-245,377-379  */
+    int32_t hold_frozen;  /* 0: v1 source -- frozen DOFs are zeroed after every predict
+                             (Filter.py:243-245); 1: frozen DOFs keep their value (what the
+                             reference's saved kf_best_mandala0_mono.txt needs)            */
+    double sigma_a[3];    /* accelerometer noise std (config.py:116-120)                   */
+    double sigma_om[3];   /* gyro noise std (config.py:106-113); the Jacobians are evaluated
+                             at n_om = sigma_om (Filter.py:330-333)                        */
+} dvi_eskf_params;
+
+/* Filter.__init__ (Filter.py:34-93): allocates device state for `batch` independent
+ * filter instances on HIP device `device`.  dtype: DVI_ESKF_F64 | DVI_ESKF_F32. */
+int dvi_eskf_create(const dvi_eskf_params* params, int64_t batch, int dtype, int device, dvi_eskf** out);
+
+/* copy.deepcopy(kf) (Simulator.py:150): independent copy incl. device buffers. */
+int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out);
+
+void dvi_eskf_destroy(dvi_eskf* h);
+
+int64_t dvi_eskf_batch(const dvi_eskf* h);
+int dvi_eskf_dtype(const dvi_eskf* h);
+
+/* Filter.update_noise_matrices / the Q, R attributes (Filter.py:67-75,110-117).  Host
+ * pointers, row-major, double.  Both must be diagonal (the reference only ever builds
+ * diagonal Q and R); otherwise DVI_ESKF_EINVAL. */
+int dvi_eskf_set_noise(dvi_eskf* h, const double* Q13x13, const double* R7x7);
+
+/* Filter.reset / the _states, _P, om_old, acc_old, R_WB_old attributes (Filter.py:44-45,
+ * 78-80,95-108).  x26 [B,26], P576 [B,24,24] (symmetric; the lower triangle is stored),
+ * om_old3 / acc_old3 [B,3]; q_old4 [B,4] is the attitude whose rotation matrix is
+ * R_WB_old -- NULL means "take it from x" (Filter.py:80).  Any other NULL leaves that
+ * part unchanged. */
+int dvi_eskf_set_state(dvi_eskf* h, const void* x26, const void* P576, const void* om_old3,
+                       const void* acc_old3, const void* q_old4, void* stream);
+int dvi_eskf_get_state(const dvi_eskf* h, void* x26, void* P576, void* om_old3, void* acc_old3,
+                       void* q_old4, void* stream);
+
+/* Filter.propagate (Filter.py:219-230): _predict_nominal + _predict_error +
+ * _predict_error_covariance + buffer swap, for every instance.
+ * dt [B] or [1]; om, acc [B,3] or [1,3] (per_instance = 0 broadcasts one sample). */
+int dvi_eskf_predict(dvi_eskf* h, const void* dt, int dt_per_instance, const void* om, const void* acc,
+                     int imu_per_instance, void* stream);
+
+/* Filter.update (Filter.py:351-395).  pos [B,3] | [1,3]; quat_xyzw [B,4] | [1,4] raw
+ * (un-normalised) measurement quaternion; notch [B] | [1].  K_out: NULL or [B,24,7]
+ * (the return value of Filter.update); status: NULL or int32 [B]. */
+int dvi_eskf_update(dvi_eskf* h, const void* pos, const void* quat_xyzw, const void* notch,
+                    int meas_per_instance, void* K_out, int32_t* status, void* stream);
+
+/* One predict followed by one update in a single launch (P makes one HBM round trip):
+ * the 1:1 epoch of Filter.run_one_epoch (Filter.py:170-185). */
+int dvi_eskf_step(dvi_eskf* h, const void* dt, int dt_per_instance, const void* om, const void* acc,
+                  int imu_per_instance, const void* pos, const void* quat_xyzw, const void* notch,
+                  int meas_per_instance, void* K_out, int32_t* status, void* stream);
+
+/* Filter.run_one_epoch with N IMU samples per camera frame (Filter.py:170-217): n_pred
+ * predicts then one update in a single launch, P resident on-chip in between.
+ * dt [n_pred,B] | [n_pred]; om/acc [n_pred,B,3] | [n_pred,3]. */
+int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_per_instance, const void* om,
+                   const void* acc, int imu_per_instance, const void* pos, const void* quat_xyzw,
+                   const void* notch, int meas_per_instance, void* K_out, int32_t* status, void* stream);
+
+/* The estimated calibration parameters, i.e. state.dofs (Filter.calculate_dof_metric,
+ * Filter.py:452-455): dofs_out [B,6].  The multi-GPU gather (RCCL all-gather of this
+ * buffer) is done by the caller -- see dvi_ekf_amd/dist.py. */
+int dvi_eskf_get_calibration(const dvi_eskf* h, void* dofs_out, void* stream);
+
+/* Raw device buffers (zero-copy views for profiling / checkpointing): packed lower
+ * triangle of P [B,300] and the persistent state block [B,36] =
+ * x26 | om_old3 | acc_old3 | q_old4. */
+void* dvi_eskf_raw_P(dvi_eskf* h);
+void* dvi_eskf_raw_x(dvi_eskf* h);
+
+/* Kernel variant selector for experiments: lanes per filter instance (64 = one
+ * wavefront per instance; 12 = five instances per wavefront, the default). */
+int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes);
+
+const char* dvi_eskf_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVI_ESKF_H */
