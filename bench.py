@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- ESKF predict+update pair-steps/s on MI355X (BASELINE.json metric).
+
+One "step" = one fused predict+update launch over the rank's batch (B = 65 536 filter
+instances per GPU, fp64, 26-state / 24 error-state), inputs and state resident in HBM.
+Workload: BASELINE config #2/#4 -- the reference's default run (mandala0_mono, default
+config.yaml) on the 1:1 schedule (dt = 1.0), per-instance perturbed initial extrinsic
+DOFs (unfrozen) and per-instance Gaussian noise on IMU and camera measurements.  The
+reference filter is dynamically unstable on long horizons, so the state is
+restored from a device snapshot every `--horizon` steps; the restore (a device-to-device
+copy of all state) is INSIDE the timed region.
+
+Single GPU:  python bench.py --steps K --warmup W
+N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                 --master-port P bench.py --gpus N --steps K --warmup W
+Ranks own disjoint instance blocks (weak scaling: 65 536 per GPU); the only collective is
+the final RCCL all-gather of the calibration estimates, inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BYTES_PER_PAIR_F64 = 5496      # 2*300w + 2*36w + 7w + 8w, w = 8
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(wl, seconds_target=12.0):
+    """Times the C oracle (oracle/eskf_oracle.c, OpenMP over instances) on a bounded sample
+    of the same workload: the first n instances, the first `horizon` pair-steps."""
+    from oracle import c_oracle
+    prm = c_oracle.make_params(wl.cfg.model.length, wl.cfg.model.angle, wl.cfg.frozen_dofs, True, wl.sigma_a,
+                               wl.sigma_om, wl.Q, wl.R)
+    cores = c_oracle.num_threads()
+    H = wl.horizon
+
+    def run(n, steps):
+        o = c_oracle.OracleBatch(prm, wl.x0[:n].cpu().numpy(), wl.P0.cpu().numpy(), wl.om0.cpu().numpy(),
+                                 wl.acc0.cpu().numpy())
+        host = [(wl.dt[k, :n].cpu().numpy(), wl.om[k, :n].cpu().numpy(), wl.acc[k, :n].cpu().numpy(),
+                 wl.pos[k, :n].cpu().numpy(), wl.quat[k, :n].cpu().numpy(), wl.notch[k, :n].cpu().numpy())
+                for k in range(steps)]
+        t0 = time.perf_counter()
+        for dt, om, acc, pos, quat, notch in host:
+            o.predict(dt, om, acc)
+            o.update(pos, quat, notch)
+        return time.perf_counter() - t0
+
+    n_probe = min(64 * cores, wl.x0.shape[0])
+    t_probe = run(n_probe, 2)
+    rate = n_probe * 2 / max(t_probe, 1e-9)
+    steps = min(H, 8)
+    n = int(min(wl.x0.shape[0], max(cores, rate * seconds_target / steps)))
+    t = run(n, steps)
+    return {"value": n * steps / t, "unit": "pair-steps/s", "cores": cores, "kind": "port",
+            "sample": f"C oracle (oracle/eskf_oracle.c, OpenMP), first {n} instances x {steps} pair-steps of the "
+                      f"same workload, {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=65536, help="filter instances per GPU")
+    ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
+    ap.add_argument("--lanes", type=int, default=0, help="lanes per instance (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dvi_ekf_amd.workloads import monte_carlo_pairs
+    B, H, K, W = args.batch, args.horizon, args.steps, args.warmup
+    wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, first_instance=rank * B)
+    f = wl.make_filter()
+    if args.lanes:
+        f.set_lanes_per_instance(args.lanes)
+    snap = f.clone()
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+
+    def step(k):
+        i = k % H
+        if i == 0:
+            f.copy_state_from(snap)
+        f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+
+    for k in range(W):
+        step(k)
+    gathered = None
+    if dist is not None:   # warm the collective up as well
+        gathered = [torch.empty((B, 6), dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, f.calibration())
+    torch.cuda.synchronize(dev)
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(K):
+        i = k % H
+        if i == 0:
+            f.copy_state_from(snap)
+        ev[k][0].record()
+        f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+        ev[k][1].record()
+    dofs = f.calibration()
+    if dist is not None:
+        dist.all_gather(gathered, dofs)     # RCCL: the only collective on the path
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # every instance must have done the full work: no singular / skipped updates, finite state
+    st = status.cpu().numpy()
+    x_fin = f.x
+    ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    if rank == 0:
+        total_pairs = float(B) * world * K
+        value = total_pairs / elapsed
+        achieved = BYTES_PER_PAIR_F64 * B / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ESKF predict+update steps/sec, 26-state, batch=65536 at 1/2/4/8 MI355X",
+            "value": value,
+            "unit": "pair-steps/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "valid": ok,
+            "config": {
+                "workload": "BASELINE config #2/#4: Monte-Carlo batch on mandala0_mono, 1:1 predict+update "
+                            "pairs (dt=1.0), unfrozen DOFs, per-instance IMU/camera noise and perturbed ICs",
+                "batch_per_gpu": B, "global_batch": B * world, "horizon_between_state_restores": H,
+                "state_restore_in_timed_region": True, "lanes_per_instance": args.lanes or 12,
+                "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "eskf_step_kernel<double,LPI>", "kernel_ms": kern_ms,
+                "algorithmic_bytes_per_launch": BYTES_PER_PAIR_F64 * B,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("benchmark invalid: an instance skipped its update or went non-finite")
+
+
+if __name__ == "__main__":
+    main()

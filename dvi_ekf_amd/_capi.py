@@ -32,6 +32,7 @@ _hpp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "dvi_eskf_create": (_i, [C.POINTER(Params), _i64, _i, _i, _hpp]),
     "dvi_eskf_clone": (_i, [_vp, _vp, _hpp]),
+    "dvi_eskf_copy_state": (_i, [_vp, _vp, _vp]),
     "dvi_eskf_destroy": (None, [_vp]),
     "dvi_eskf_batch": (_i64, [_vp]),
     "dvi_eskf_dtype": (_i, [_vp]),

@@ -70,6 +70,10 @@ class BatchedESKF:
     def __deepcopy__(self, memo):
         return self.clone()
 
+    def copy_state_from(self, other: "BatchedESKF") -> None:
+        """Device-to-device restore of x, P and the buffers from another handle."""
+        _capi.check(self.lib.dvi_eskf_copy_state(self._h, other._h, self._stream()), "dvi_eskf_copy_state")
+
     # -- helpers ---------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

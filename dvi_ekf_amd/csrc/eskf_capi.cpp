@@ -124,6 +124,18 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     return DVI_ESKF_OK;
 }
 
+int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
+    if (!dst || !src || dst->B != src->B || dst->dtype != src->dtype || dst->device != src->device) return DVI_ESKF_EINVAL;
+    DeviceGuard g(src->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    const size_t es = elem_size(src->dtype);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(dst->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(dst->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return DVI_ESKF_EHIP;
+    return DVI_ESKF_OK;
+}
+
 void dvi_eskf_destroy(dvi_eskf* h) {
     if (!h) return;
     DeviceGuard g(h->device);

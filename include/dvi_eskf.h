@@ -68,6 +68,11 @@ int dvi_eskf_create(const dvi_eskf_params* params, int64_t batch, int dtype, int
 /* copy.deepcopy(kf) (Simulator.py:150): independent copy incl. device buffers. */
 int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out);
 
+/* dst <- src (device-to-device copy of the state records; same batch and dtype).  The
+ * checkpoint/restore primitive behind Filter.reset (Filter.py:95-108) and
+ * Simulator.reset_kf (Simulator.py:160-161) when the initial state is kept on the device. */
+int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream);
+
 void dvi_eskf_destroy(dvi_eskf* h);
 
 int64_t dvi_eskf_batch(const dvi_eskf* h);
