@@ -60,6 +60,9 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP library is required (build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C dvi_ekf_amd/csrc`)")
+        # PyTorch must be loaded first: the library has to bind to the HIP runtime that
+        # PyTorch ships, otherwise torch's streams / device pointers belong to another runtime
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the symbol is missing
