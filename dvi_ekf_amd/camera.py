@@ -105,6 +105,9 @@ class VisualTraj:
             Quaternion(x=self.qx[i], y=self.qy[i], z=self.qz[i], w=self.qw[i], do_normalise=True)
             for i in range(len(self.qw))
         ]
+        # extrinsic xyz Euler angles in degrees (VisualTrajectory.py:151-162)
+        eul = np.array([q.euler_xyz_deg for q in self.quats])
+        self.rx_deg, self.ry_deg, self.rz_deg = eul[:, 0], eul[:, 1], eul[:, 2]
 
     def at_index(self, index: int) -> VisualMeasurementPoint:
         q = Quaternion(x=self.qx[index], y=self.qy[index], z=self.qz[index], w=self.qw[index])
