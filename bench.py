@@ -176,7 +176,7 @@ def main():
                 "workload": "BASELINE config #2/#4: Monte-Carlo batch on mandala0_mono, 1:1 predict+update "
                             "pairs (dt=1.0), unfrozen DOFs, per-instance IMU/camera noise and perturbed ICs",
                 "batch_per_gpu": B, "global_batch": B * world, "horizon_between_state_restores": H,
-                "state_restore_in_timed_region": True, "lanes_per_instance": args.lanes or 12,
+                "state_restore_in_timed_region": True, "lanes_per_instance": args.lanes or 32,
                 "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
             },
             "roofline": {

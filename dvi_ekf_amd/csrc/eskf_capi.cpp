@@ -15,13 +15,62 @@ struct dvi_eskf {
     int device;
     int lpi;
     eskf::HostParams hp;
-    void* d_P;   // [B][300]
-    void* d_x;   // [B][36]
+    void* d_P;   // [B][300] packed covariance
+    void* d_x;   // [36][B]  state record, structure-of-arrays
+    // workspace of the step pipeline (pre -> cov -> post kernels)
+    void* d_J;          // [jcap][B][JAC_WORDS]
+    int jcap;           // predicts per launch the Jacobian workspace can hold
+    void* d_res;        // [B][8]
+    void* d_e;          // [B][24]
+    int32_t* d_status;  // [B]
 };
 
 namespace {
 
 size_t elem_size(int dtype) { return dtype == DVI_ESKF_F64 ? sizeof(double) : sizeof(float); }
+
+void free_buffers(dvi_eskf* h) {
+    if (h->d_P) (void)hipFree(h->d_P);
+    if (h->d_x) (void)hipFree(h->d_x);
+    if (h->d_J) (void)hipFree(h->d_J);
+    if (h->d_res) (void)hipFree(h->d_res);
+    if (h->d_e) (void)hipFree(h->d_e);
+    if (h->d_status) (void)hipFree(h->d_status);
+    h->d_P = h->d_x = h->d_J = h->d_res = h->d_e = nullptr;
+    h->d_status = nullptr;
+    h->jcap = 0;
+}
+
+// state records + single-predict workspace; false on allocation failure (buffers freed)
+bool alloc_buffers(dvi_eskf* h) {
+    const size_t es = elem_size(h->dtype);
+    const size_t B = (size_t)h->B;
+    h->d_P = h->d_x = h->d_J = h->d_res = h->d_e = nullptr;
+    h->d_status = nullptr;
+    h->jcap = 0;
+    if (hipMalloc(&h->d_P, B * 300 * es) != hipSuccess || hipMalloc(&h->d_x, B * 36 * es) != hipSuccess ||
+        hipMalloc(&h->d_J, B * eskf::JAC_WORDS * es) != hipSuccess || hipMalloc(&h->d_res, B * 8 * es) != hipSuccess ||
+        hipMalloc(&h->d_e, B * 24 * es) != hipSuccess ||
+        hipMalloc((void**)&h->d_status, B * sizeof(int32_t)) != hipSuccess) {
+        free_buffers(h);
+        return false;
+    }
+    h->jcap = 1;
+    return true;
+}
+
+// grow the Jacobian workspace for an n_pred-step epoch (allocation: not graph-capturable;
+// happens once per handle and epoch length)
+bool ensure_jcap(dvi_eskf* h, int n_pred) {
+    if (n_pred <= h->jcap) return true;
+    void* nj = nullptr;
+    if (hipMalloc(&nj, (size_t)n_pred * (size_t)h->B * eskf::JAC_WORDS * elem_size(h->dtype)) != hipSuccess) return false;
+    (void)hipDeviceSynchronize();   // earlier launches may still read the old workspace
+    (void)hipFree(h->d_J);
+    h->d_J = nj;
+    h->jcap = n_pred;
+    return true;
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -46,8 +95,10 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     if (n_pred == 0 && !do_update) return DVI_ESKF_OK;
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
+    if (!ensure_jcap(h, n_pred)) return DVI_ESKF_ENOMEM;
     eskf::StepArgs a;
     a.P = h->d_P; a.xs = h->d_x;
+    a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status;
     a.dt = dt; a.om = om; a.acc = acc;
     a.pos = pos; a.quat = quat; a.notch = notch;
     a.K_out = do_update ? K_out : nullptr;
@@ -76,7 +127,7 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     if (!g.ok) return DVI_ESKF_ENODEV;
     dvi_eskf* h = new (std::nothrow) dvi_eskf();
     if (!h) return DVI_ESKF_ENOMEM;
-    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 12;
+    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 32;
     h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
     h->hp.frozen_mask = 0;
     for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);
@@ -85,10 +136,7 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     for (int i = 0; i < 13; ++i) h->hp.qd[i] = 1.0;   // Q = eye before set_noise (Filter.py:68)
     for (int i = 0; i < 7; ++i) h->hp.r[i] = 1.0;
     const size_t es = elem_size(dtype);
-    h->d_P = nullptr; h->d_x = nullptr;
-    if (hipMalloc(&h->d_P, (size_t)batch * 300 * es) != hipSuccess ||
-        hipMalloc(&h->d_x, (size_t)batch * 36 * es) != hipSuccess) {
-        if (h->d_P) (void)hipFree(h->d_P);
+    if (!alloc_buffers(h)) {
         delete h;
         return DVI_ESKF_ENOMEM;
     }
@@ -106,17 +154,14 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     dvi_eskf* h = new (std::nothrow) dvi_eskf(*src);
     if (!h) return DVI_ESKF_ENOMEM;
     const size_t es = elem_size(src->dtype);
-    h->d_P = nullptr; h->d_x = nullptr;
-    if (hipMalloc(&h->d_P, (size_t)src->B * 300 * es) != hipSuccess ||
-        hipMalloc(&h->d_x, (size_t)src->B * 36 * es) != hipSuccess) {
-        if (h->d_P) (void)hipFree(h->d_P);
+    if (!alloc_buffers(h)) {
         delete h;
         return DVI_ESKF_ENOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(h->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(h->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        (void)hipFree(h->d_P); (void)hipFree(h->d_x);
+        free_buffers(h);
         delete h;
         return DVI_ESKF_EHIP;
     }
@@ -139,8 +184,7 @@ int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
 void dvi_eskf_destroy(dvi_eskf* h) {
     if (!h) return;
     DeviceGuard g(h->device);
-    if (h->d_P) (void)hipFree(h->d_P);
-    if (h->d_x) (void)hipFree(h->d_x);
+    free_buffers(h);
     delete h;
 }
 
@@ -220,7 +264,7 @@ void* dvi_eskf_raw_x(dvi_eskf* h) { return h ? h->d_x : nullptr; }
 
 int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes) {
     if (!h) return DVI_ESKF_EINVAL;
-    if (lanes != 64 && lanes != 32 && lanes != 16 && lanes != 12 && lanes != 8) return DVI_ESKF_EINVAL;
+    if (lanes != 64 && lanes != 32 && lanes != 24 && lanes != 16 && lanes != 12 && lanes != 8) return DVI_ESKF_EINVAL;
     h->lpi = lanes;
     return DVI_ESKF_OK;
 }

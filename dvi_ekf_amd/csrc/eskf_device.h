@@ -10,6 +10,7 @@ namespace eskf {
 
 constexpr int DVI_STATUS_SINGULAR = 1;
 constexpr int DVI_STATUS_NONFINITE = 2;
+constexpr int JAC_WORDS = 88;   // words per Jacobian record (eskf_kernels.hip: JW)
 
 // constants of one filter configuration, in the kernel's working precision; passed by value
 // as a kernel argument (lives in SGPRs / the kernarg segment)
@@ -57,7 +58,12 @@ struct StepArgs {
     const void* quat;   // [B][4] or [4]
     const void* notch;  // [B] or [1]
     void* K_out;        // nullable [B][24][7]
-    int32_t* status;    // nullable [B]
+    int32_t* status;    // nullable [B] (caller's)
+    // workspace owned by the handle
+    void* J;            // [n_pred][B][88] Jacobian records written by the pre kernel
+    void* res;          // [B][8]  residual (7) + asin-clamp flag
+    void* e;            // [B][24] error state of the update
+    int32_t* status_ws; // [B]
     int64_t B;
     int n_pred;
     int do_update;

@@ -363,14 +363,156 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
 }
 
 // ----------------------------------------------------------------------------------
-// LDS region of one instance (units of T)
+// Work split (round-1 v2).  The per-instance "scalar" arithmetic -- probe trigonometry,
+// nominal propagation, Jacobian blocks, residual, injection -- does not depend on the
+// covariance, and CDNA4 has no scalar fp64 ALU: evaluated inside a wave that is shared by a
+// few instances it costs a full wave issue per instruction.  It therefore runs in two small
+// lane-per-instance kernels (64 instances per wave, every lane useful):
+//
+//   eskf_pre_kernel   x, IMU samples, measurement -> predicted x, Jacobian blocks J[n], residual
+//   eskf_cov_kernel   P, J[n], residual           -> P, error state e, status      (LPI lanes / instance)
+//   eskf_post_kernel  predicted x, e, status      -> x                              (injection)
+//
+// The nominal state never reads P, so one pre-launch covers all n_pred predicts of an epoch
+// and the covariance kernel runs them back to back with P resident in LDS.
+// ----------------------------------------------------------------------------------
+constexpr int JW = 88;          // words per Jacobian record: A9 Th9 Bm9 Cm18 Dm12 Em9 dt1 | N6 18 | pad
+constexpr int J_A = 0, J_TH = 9, J_BM = 18, J_CM = 27, J_DM = 45, J_EM = 57, J_DT = 66, J_N6 = 67;
+constexpr int J_CORE = 67, J_FULL = 85;
+
+template <typename T>
+__device__ __forceinline__ void store_jac(const Jac<T>& J, T* g, bool with_n6) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { g[J_A + i] = J.A[i]; g[J_TH + i] = J.Th[i]; g[J_BM + i] = J.Bm[i]; g[J_EM + i] = J.Em[i]; }
+#pragma unroll
+    for (int i = 0; i < 18; ++i) g[J_CM + i] = J.Cm[i];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) g[J_DM + i] = J.Dm[i];
+    g[J_DT] = J.dt;
+    if (with_n6) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) g[J_N6 + i] = J.N6[i];
+    }
+}
+
+// state record, structure-of-arrays: word w of instance b at xs[w * B + b]
+// words: x26 | om_old3 | acc_old3 | q_old4
+template <typename T>
+__device__ __forceinline__ void load_state(const T* xs, int64_t B, int64_t b, State<T>& s) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        s.p[i] = xs[(0 + i) * B + b]; s.v[i] = xs[(3 + i) * B + b]; s.notch[i] = xs[(16 + i) * B + b];
+        s.pc[i] = xs[(19 + i) * B + b]; s.om_o[i] = xs[(26 + i) * B + b]; s.acc_o[i] = xs[(29 + i) * B + b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s.q[i] = xs[(6 + i) * B + b]; s.qc[i] = xs[(22 + i) * B + b]; s.qo[i] = xs[(32 + i) * B + b]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s.dofs[i] = xs[(10 + i) * B + b];
+}
+template <typename T>
+__device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const State<T>& s) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xs[(0 + i) * B + b] = s.p[i]; xs[(3 + i) * B + b] = s.v[i]; xs[(16 + i) * B + b] = s.notch[i];
+        xs[(19 + i) * B + b] = s.pc[i]; xs[(26 + i) * B + b] = s.om_o[i]; xs[(29 + i) * B + b] = s.acc_o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xs[(6 + i) * B + b] = s.q[i]; xs[(22 + i) * B + b] = s.qc[i]; xs[(32 + i) * B + b] = s.qo[i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xs[(10 + i) * B + b] = s.dofs[i];
+}
+
+// ---- lane-per-instance: nominal propagation + Jacobian blocks + residual ---------------------
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    T* xs = reinterpret_cast<T*>(a.xs);
+    State<T> s;
+    load_state(xs, a.B, b, s);
+    for (int ip = 0; ip < a.n_pred; ++ip) {
+        const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
+        const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
+        const T* gom = reinterpret_cast<const T*>(a.om) + so;
+        const T* gac = reinterpret_cast<const T*>(a.acc) + so;
+        const T dt = gdt[0];
+        T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
+        Jac<T> J;
+        predict_scalar(s, prm, dt, om_n, acc_n, J);
+        store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, prm.q_gyro != 0);
+    }
+    if (a.do_update) {
+        // measurement correction and residual (Filter.py:364-375)
+        const int64_t mo = a.meas_stride ? b : 0;
+        const T* gpos = reinterpret_cast<const T*>(a.pos) + mo * 3;
+        const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
+        const T ang_notch = reinterpret_cast<const T*>(a.notch)[mo];
+        T qraw[4] = {gq[0], gq[1], gq[2], gq[3]};
+        T nq[4] = {T(0), T(0), T(0), T(1)};
+        t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
+        T qm[4], qe[4];
+        quat_mul(nq, qraw, qm);
+        quat_nrm(qm);
+        qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
+        quat_mul(qm, s.qc, qe);
+        quat_nrm(qe);
+        T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
+        T flag = T(0);
+        if (nv > T(1)) { nv = T(1); flag = T(1); }
+        const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+        const T f = (nv == T(0)) ? T(0) : ang / nv;
+        T* gr = reinterpret_cast<T*>(a.res) + b * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { gr[i] = gpos[i] - s.pc[i]; gr[3 + i] = f * qe[i]; }
+        gr[6] = ang_notch - s.notch[0];
+        gr[7] = flag;                                         // asin argument was clamped
+    }
+    if (a.n_pred > 0) store_state(xs, a.B, b, s);
+}
+
+// ---- lane-per-instance: error injection (ErrorState.from_array state.py:105-129, State.__add__ 46-60)
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T> prm) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int st = a.status_ws[b];
+    if (a.status) a.status[b] = st;
+    if (st & DVI_STATUS_SINGULAR) return;                     // Filter.py:356-361: nothing changes
+    T* xs = reinterpret_cast<T*>(a.xs);
+    const T* e = reinterpret_cast<const T*>(a.e) + b * 24;
+    T q[4], qc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { q[i] = xs[(6 + i) * a.B + b]; qc[i] = xs[(22 + i) * a.B + b]; }
+    T th[3] = {e[6], e[7], e[8]}, thc[3] = {e[21], e[22], e[23]};
+    T dq[4], dqc[4], qn[4], qcn[4];
+    quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
+    quat_about_axis(t_sqrt(thc[0] * thc[0] + thc[1] * thc[1] + thc[2] * thc[2]), th, dqc);   // sic (state.py:124)
+    quat_mul(q, dq, qn);
+    quat_nrm(qn);
+    quat_mul(qc, dqc, qcn);
+    quat_nrm(qcn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        xs[(0 + i) * a.B + b] += e[i];
+        xs[(3 + i) * a.B + b] += e[3 + i];
+        xs[(16 + i) * a.B + b] += e[15 + i];
+        xs[(19 + i) * a.B + b] += e[18 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xs[(10 + i) * a.B + b] += e[9 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xs[(6 + i) * a.B + b] = qn[i]; xs[(22 + i) * a.B + b] = qcn[i]; }
+}
+
+// ----------------------------------------------------------------------------------
+// covariance kernel: LDS region of one instance (units of T)
 // ----------------------------------------------------------------------------------
 constexpr int PS = 25;             // row stride of P
 constexpr int OFF_P = 0;           // 24 x 25
 constexpr int OFF_S = 600;         // scratch: U 6x24 (predict) | Z 24x7 (update)
-constexpr int OFF_X = 768;         // 36 state words (+4 pad)
-constexpr int OFF_E = 808;         // 24 error-state words
-constexpr int REGION_MIN = 832;
+constexpr int OFF_J = 768;         // Jacobian record of the current predict (85 words) | L, 1/D, res (update)
+constexpr int OFF_E = 856;         // 24 error-state words
+constexpr int REGION_MIN = 880;
 // regions of the instances sharing a wave are staggered so that their windows fall on
 // different banks: REGION = LPI (mod 32) (conflict-free for the 8-byte accesses below)
 __host__ __device__ constexpr int region_words(int lpi) {
@@ -381,6 +523,10 @@ __host__ __device__ constexpr int region_words(int lpi) {
 
 __device__ __forceinline__ void group_sync() { __syncthreads(); }   // block == one wavefront
 
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
 // packed index -> (i, j), i >= j
 __device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
     const int r = e / 25, c = e - 25 * r;
@@ -388,7 +534,7 @@ __device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
 }
 
 template <typename T, int LPI>
-__global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
+__global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> prm) {
     constexpr int G = 64 / LPI;
     constexpr int REGION = region_words(LPI);
     __shared__ T smem[G * REGION];
@@ -401,46 +547,81 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
 
     T* sP = smem + grp * REGION + OFF_P;
     T* sS = smem + grp * REGION + OFF_S;
-    T* sX = smem + grp * REGION + OFF_X;
+    T* sJ = smem + grp * REGION + OFF_J;
     T* sE = smem + grp * REGION + OFF_E;
-
     T* gP = reinterpret_cast<T*>(a.P) + inst * 300;
-    T* gX = reinterpret_cast<T*>(a.xs) + inst * 36;
 
-    // ---- load: packed P -> full symmetric LDS image, state words -> LDS --------------
-    for (int e = lig; e < 300; e += LPI) {
-        int i, j;
-        unpack_ij(e, i, j);
-        const T v = gP[e];
-        sP[i * PS + j] = v;
-        sP[j * PS + i] = v;
+    const int jwords = prm.q_gyro ? J_FULL : J_CORE;
+    constexpr int NJ = (J_FULL + LPI - 1) / LPI;     // Jacobian words per lane (upper bound)
+
+    // ---- load: packed P -> full symmetric LDS image.  All global loads are issued before the
+    // first LDS write so that their latencies overlap (one HBM round trip per wave, not one
+    // per element).
+    {
+        using T2 = typename Vec2<T>::type;
+        constexpr int NV = (150 + LPI - 1) / LPI;    // 16-byte (2-word) pieces per lane
+        const T2* gP2 = reinterpret_cast<const T2*>(gP);
+        T2 v[NV];
+        T jv[NJ];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e2 = lig + k * LPI;
+            if (e2 < 150) v[k] = gP2[e2];
+        }
+        if (a.n_pred > 0) {
+            const T* gJ = reinterpret_cast<const T*>(a.J) + inst * JW;
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) {
+                const int e = lig + k * LPI;
+                if (e < jwords) jv[k] = gJ[e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e2 = lig + k * LPI;
+            if (e2 < 150) {
+                int i, j;
+                unpack_ij(2 * e2, i, j);
+                sP[i * PS + j] = v[k].x;
+                sP[j * PS + i] = v[k].x;
+                unpack_ij(2 * e2 + 1, i, j);
+                sP[i * PS + j] = v[k].y;
+                sP[j * PS + i] = v[k].y;
+            }
+        }
+        if (a.n_pred > 0) {
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) {
+                const int e = lig + k * LPI;
+                if (e < jwords) sJ[e] = jv[k];
+            }
+        }
     }
-    for (int e = lig; e < 36; e += LPI) sX[e] = gX[e];
-    group_sync();
-
-    State<T> s;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { s.p[i] = sX[i]; s.v[i] = sX[3 + i]; s.notch[i] = sX[16 + i]; s.pc[i] = sX[19 + i];
-                                  s.om_o[i] = sX[26 + i]; s.acc_o[i] = sX[29 + i]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { s.q[i] = sX[6 + i]; s.qc[i] = sX[22 + i]; s.qo[i] = sX[32 + i]; }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) s.dofs[i] = sX[10 + i];
 
     // ================================ predict(s) =======================================
     for (int ip = 0; ip < a.n_pred; ++ip) {
-        T dt, om_n[3], acc_n[3];
-        {
-            const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + inst : ip);
-            const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + inst) * 3 : (int64_t)ip * 3;
-            const T* gom = reinterpret_cast<const T*>(a.om) + so;
-            const T* gac = reinterpret_cast<const T*>(a.acc) + so;
-            dt = gdt[0];
+        if (ip > 0) {   // (the record of the first predict was fetched together with P)
+            const T* gJ = reinterpret_cast<const T*>(a.J) + ((int64_t)ip * a.B + inst) * JW;
+            T jv[NJ];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { om_n[i] = gom[i]; acc_n[i] = gac[i]; }
+            for (int k = 0; k < NJ; ++k) {
+                const int e = lig + k * LPI;
+                if (e < jwords) jv[k] = gJ[e];
+            }
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) {
+                const int e = lig + k * LPI;
+                if (e < jwords) sJ[e] = jv[k];
+            }
         }
-        Jac<T> J;
-        predict_scalar(s, prm, dt, om_n, acc_n, J);
+        group_sync();
+        const T dt = sJ[J_DT];
+        const T* A = sJ + J_A;
+        const T* Th = sJ + J_TH;
+        const T* Bm = sJ + J_BM;
+        const T* Cm = sJ + J_CM;
+        const T* Dm = sJ + J_DM;
+        const T* Em = sJ + J_EM;
 
         // ---- phase 1: lane owns column j.  U[:,j] = Fx[18:24,:] P[:,j]; then the row
         // operations of Faa = Fx[0:18,0:18] on column j (rows 0:9, 15, 16), all from the
@@ -453,15 +634,15 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
             for (int r = 0; r < 3; ++r) {
                 T u = dt * c[3 + r] + c[16 + r];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) u += J.Bm[3 * r + k] * c[6 + k];
+                for (int k = 0; k < 3; ++k) u += Bm[3 * r + k] * c[6 + k];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) u += J.Cm[6 * r + k] * c[9 + k];
+                for (int k = 0; k < 6; ++k) u += Cm[6 * r + k] * c[9 + k];
                 sS[r * 24 + j] = u;
-                T w = J.Dm[4 * r + 3] * c[15];
+                T w = Dm[4 * r + 3] * c[15];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) w += J.Dm[4 * r + k] * c[9 + k];
+                for (int k = 0; k < 3; ++k) w += Dm[4 * r + k] * c[9 + k];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) w += J.Em[3 * r + k] * c[19 + k];
+                for (int k = 0; k < 3; ++k) w += Em[3 * r + k] * c[19 + k];
                 if (r == 1) w += c[22];
                 if (r == 2) w += c[23];
                 sS[(3 + r) * 24 + j] = w;
@@ -470,8 +651,8 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     sP[r * PS + j] = c[r] + dt * c[3 + r];
-                    sP[(3 + r) * PS + j] = c[3 + r] + J.A[3 * r] * c[6] + J.A[3 * r + 1] * c[7] + J.A[3 * r + 2] * c[8];
-                    sP[(6 + r) * PS + j] = J.Th[3 * r] * c[6] + J.Th[3 * r + 1] * c[7] + J.Th[3 * r + 2] * c[8];
+                    sP[(3 + r) * PS + j] = c[3 + r] + A[3 * r] * c[6] + A[3 * r + 1] * c[7] + A[3 * r + 2] * c[8];
+                    sP[(6 + r) * PS + j] = Th[3 * r] * c[6] + Th[3 * r + 1] * c[7] + Th[3 * r + 2] * c[8];
                 }
                 sP[15 * PS + j] = c[15] + dt * c[16];
                 sP[16 * PS + j] = c[16] + dt * c[17];
@@ -493,8 +674,8 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     n[r] = c[r] + dt * c[3 + r];
-                    n[3 + r] = c[3 + r] + J.A[3 * r] * c[6] + J.A[3 * r + 1] * c[7] + J.A[3 * r + 2] * c[8];
-                    n[6 + r] = J.Th[3 * r] * c[6] + J.Th[3 * r + 1] * c[7] + J.Th[3 * r + 2] * c[8];
+                    n[3 + r] = c[3 + r] + A[3 * r] * c[6] + A[3 * r + 1] * c[7] + A[3 * r + 2] * c[8];
+                    n[6 + r] = Th[3 * r] * c[6] + Th[3 * r + 1] * c[7] + Th[3 * r + 2] * c[8];
                 }
                 const T n15 = c15 + dt * c16, n16 = c16 + dt * c17;
 #pragma unroll
@@ -520,15 +701,15 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
                 for (int b = 0; b < 3; ++b) {
                     T x = dt * u[3 + b] + u[16 + b];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) x += J.Bm[3 * b + k] * u[6 + k];
+                    for (int k = 0; k < 3; ++k) x += Bm[3 * b + k] * u[6 + k];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) x += J.Cm[6 * b + k] * u[9 + k];
+                    for (int k = 0; k < 6; ++k) x += Cm[6 * b + k] * u[9 + k];
                     row[18 + b] = x;
-                    T y = J.Dm[4 * b + 3] * u[15];
+                    T y = Dm[4 * b + 3] * u[15];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) y += J.Dm[4 * b + k] * u[9 + k];
+                    for (int k = 0; k < 3; ++k) y += Dm[4 * b + k] * u[9 + k];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) y += J.Em[3 * b + k] * u[19 + k];
+                    for (int k = 0; k < 3; ++k) y += Em[3 * b + k] * u[19 + k];
                     if (b == 1) y += u[22];
                     if (b == 2) y += u[23];
                     row[21 + b] = y;
@@ -537,8 +718,8 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     row[r] = u[r] + dt * u[3 + r];
-                    row[3 + r] = u[3 + r] + J.A[3 * r] * u[6] + J.A[3 * r + 1] * u[7] + J.A[3 * r + 2] * u[8];
-                    row[6 + r] = J.Th[3 * r] * u[6] + J.Th[3 * r + 1] * u[7] + J.Th[3 * r + 2] * u[8];
+                    row[3 + r] = u[3 + r] + A[3 * r] * u[6] + A[3 * r + 1] * u[7] + A[3 * r + 2] * u[8];
+                    row[6 + r] = Th[3 * r] * u[6] + Th[3 * r + 1] * u[7] + Th[3 * r + 2] * u[8];
                 }
 #pragma unroll
                 for (int k = 9; k < 15; ++k) row[k] = u[k];
@@ -546,19 +727,16 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
                 row[16] = u[16] + dt * u[17];
                 row[17] = u[17];
                 if (prm.q_gyro) {   // Fi[6:9,3:6] = I couples the gyro noise into the camera rows
+                    const T* N6 = sJ + J_N6;
                     T nr[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        // N6[ar][k] with a runtime row index: select
-                        T v = J.N6[k];
-#pragma unroll
-                        for (int rr = 1; rr < 6; ++rr) v = (ar == rr) ? J.N6[3 * rr + k] : v;
-                        nr[k] = v * prm.qd[3 + k];
+                        nr[k] = N6[3 * ar + k] * prm.qd[3 + k];
                         row[6 + k] += nr[k];
                     }
 #pragma unroll
                     for (int b = 0; b < 6; ++b)
-                        row[18 + b] += nr[0] * J.N6[3 * b] + nr[1] * J.N6[3 * b + 1] + nr[2] * J.N6[3 * b + 2];
+                        row[18 + b] += nr[0] * N6[3 * b] + nr[1] * N6[3 * b + 1] + nr[2] * N6[3 * b + 2];
                 }
 #pragma unroll
                 for (int k = 0; k < 24; ++k) sP[(18 + ar) * PS + k] = row[k];
@@ -570,9 +748,9 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
     }
 
     // ================================ update ===========================================
-    int status = 0;
     if (a.do_update) {
-        // ---- scalar: S = H P H^T + R (H selects rows 18..23,15: Filter.py:83-85), LDL^T ----
+        // ---- S = H P H^T + R (H selects rows 18..23,15: Filter.py:83-85), LDL^T.  Every lane
+        // of the instance factorises redundantly (7 pivots, ~60 fma) ---------------------
         constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
         T Lm[21], d[7], rd[7];   // unit-lower L packed by rows: L[i][j] at i(i-1)/2 + j
         bool ok = true;
@@ -599,32 +777,12 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
                 }
             }
         }
-        if (!ok) status |= DVI_STATUS_SINGULAR;
-
-        // ---- scalar: measurement correction and residual (Filter.py:364-375) ---------------
+        const T* gres = reinterpret_cast<const T*>(a.res) + inst * 8;
         T res[7];
-        {
-            const int64_t mo = a.meas_stride ? inst : 0;
-            const T* gpos = reinterpret_cast<const T*>(a.pos) + mo * 3;
-            const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
-            const T ang_notch = reinterpret_cast<const T*>(a.notch)[mo];
-            T qraw[4] = {gq[0], gq[1], gq[2], gq[3]};
-            T nq[4] = {T(0), T(0), T(0), T(1)};
-            t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
-            T qm[4], qe[4];
-            quat_mul(nq, qraw, qm);
-            quat_nrm(qm);
-            qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
-            quat_mul(qm, s.qc, qe);
-            quat_nrm(qe);
-            T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
-            if (nv > T(1)) { nv = T(1); status |= DVI_STATUS_NONFINITE; }
-            const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
-            const T f = (nv == T(0)) ? T(0) : ang / nv;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) { res[i] = gpos[i] - s.pc[i]; res[3 + i] = f * qe[i]; }
-            res[6] = ang_notch - s.notch[0];
-        }
+        for (int m = 0; m < 7; ++m) res[m] = gres[m];
+        int status = ok ? 0 : DVI_STATUS_SINGULAR;
+        if (gres[7] != T(0)) status |= DVI_STATUS_NONFINITE;
 
         // ---- phase 3: lane owns row i: Z[i,:] L^T = P[i,sel]; K[i,:] = (Z D^-1) L^-1; e_i = K[i,:] res
         if (ok) {
@@ -649,6 +807,7 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
                 for (int m = 0; m < 7; ++m) { e += k[m] * res[m]; sS[i * 7 + m] = z[m]; }
                 if (i >= 9 && i < 15 && ((prm.frozen_mask >> (i - 9)) & 1)) e = T(0);   // Filter.py:377-379
                 sE[i] = e;
+                reinterpret_cast<T*>(a.e)[inst * 24 + i] = e;
                 if (a.K_out) {
                     T* gK = reinterpret_cast<T*>(a.K_out) + (inst * 24 + i) * 7;
 #pragma unroll
@@ -657,35 +816,13 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
             }
         }
         group_sync();
-
-        T Gt[3], Gc[3];   // half error angles for the reset Jacobian
         if (ok) {
-            // ---- scalar: ErrorState.from_array (state.py:105-129) + State.__add__ (46-60)
-            T e[24];
-#pragma unroll
-            for (int i = 0; i < 24; ++i) e[i] = sE[i];
-            const T* th = e + 6;
-            const T* thc = e + 21;
-            T dq[4], dqc[4], qn[4], qcn[4];
-            quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
-            quat_about_axis(t_sqrt(thc[0] * thc[0] + thc[1] * thc[1] + thc[2] * thc[2]), th, dqc);   // sic (state.py:124)
-            quat_mul(s.q, dq, qn);
-            quat_nrm(qn);
-            quat_mul(s.qc, dqc, qcn);
-            quat_nrm(qcn);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                s.p[i] += e[i]; s.v[i] += e[3 + i]; s.notch[i] += e[15 + i]; s.pc[i] += e[18 + i];
-                Gt[i] = T(0.5) * th[i]; Gc[i] = T(0.5) * thc[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) s.dofs[i] += e[9 + i];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { s.q[i] = qn[i]; s.qc[i] = qcn[i]; }
+            // half error angles of the reset Jacobian (Filter.py:387-390)
+            const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
+            const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
 
             // ---- phase 4: lane owns column j.  P[:,j] -= Z (D^-1 Z[j,:]^T)  (Joseph form with the
-            // optimal gain, Filter.py:383-384), then the row part of the reset G P G^T
-            // (Filter.py:387-390) on its own column.
+            // optimal gain, Filter.py:383-384), then the row part of the reset G P G^T on its column.
             for (int j = lig; j < 24; j += LPI) {
                 T zd[7];
 #pragma unroll
@@ -698,7 +835,6 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
                     for (int m = 0; m < 7; ++m) v -= sS[i * 7 + m] * zd[m];
                     c[i] = v;
                 }
-                // rows 6:9 <- (I - [Gt]x) rows 6:9 ; rows 21:24 <- (I - [Gc]x) rows 21:24
                 {
                     const T a0 = c[6], a1 = c[7], a2 = c[8];
                     c[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
@@ -715,6 +851,8 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
         }
         group_sync();
         if (ok) {
+            const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
+            const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
             // ---- phase 5: lane owns row i: column part of the reset.
             for (int i = lig; i < 24; i += LPI) {
                 const T a0 = sP[i * PS + 6], a1 = sP[i * PS + 7], a2 = sP[i * PS + 8];
@@ -728,25 +866,30 @@ __global__ __launch_bounds__(64) void eskf_step_kernel(StepArgs a, DevParams<T> 
             }
         }
         group_sync();
-        if (a.status && lig == 0) a.status[inst] = status;
+        if (lig == 0) a.status_ws[inst] = status;
     }
 
-    // ---- store ---------------------------------------------------------------------------
+    // ---- store: lower triangle -> packed record (16-byte stores) --------------------------
+    {
+        using T2 = typename Vec2<T>::type;
+        constexpr int NV = (150 + LPI - 1) / LPI;
+        T2* gP2 = reinterpret_cast<T2*>(gP);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { sX[i] = s.p[i]; sX[3 + i] = s.v[i]; sX[16 + i] = s.notch[i]; sX[19 + i] = s.pc[i];
-                                  sX[26 + i] = s.om_o[i]; sX[29 + i] = s.acc_o[i]; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { sX[6 + i] = s.q[i]; sX[22 + i] = s.qc[i]; sX[32 + i] = s.qo[i]; }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) sX[10 + i] = s.dofs[i];
-    group_sync();
-    for (int e = lig; e < 36; e += LPI) gX[e] = sX[e];
-    for (int e = lig; e < 300; e += LPI) {
-        int i, j;
-        unpack_ij(e, i, j);
-        gP[e] = sP[i * PS + j];
+        for (int k = 0; k < NV; ++k) {
+            const int e2 = lig + k * LPI;
+            if (e2 < 150) {
+                int i, j;
+                T2 v;
+                unpack_ij(2 * e2, i, j);
+                v.x = sP[i * PS + j];
+                unpack_ij(2 * e2 + 1, i, j);
+                v.y = sP[i * PS + j];
+                gP2[e2] = v;
+            }
+        }
     }
 }
+
 
 // ----------------------------------------------------------------------------------
 // state import / export between the user-facing layout and the device records
@@ -764,8 +907,8 @@ __global__ void pack_state_kernel(int64_t B, const T* x26, const T* P576, const 
         }
     }
     for (int64_t t = tid; t < B * 36; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = t / 36;
-        const int w = (int)(t - b * 36);
+        const int w = (int)(t / B);               // structure-of-arrays record: xs[w * B + b]
+        const int64_t b = t - (int64_t)w * B;
         if (w < 26) { if (x26) xs[t] = x26[b * 26 + w]; }
         else if (w < 29) { if (om3) xs[t] = om3[b * 3 + (w - 26)]; }
         else if (w < 32) { if (acc3) xs[t] = acc3[b * 3 + (w - 29)]; }
@@ -791,8 +934,8 @@ __global__ void unpack_state_kernel(int64_t B, const T* xs, const T* Ppk, T* x26
         }
     }
     for (int64_t t = tid; t < B * 36; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = t / 36;
-        const int w = (int)(t - b * 36);
+        const int w = (int)(t / B);
+        const int64_t b = t - (int64_t)w * B;
         const T v = xs[t];
         if (w < 26) { if (x26) x26[b * 26 + w] = v; if (dofs6 && w >= 10 && w < 16) dofs6[b * 6 + (w - 10)] = v; }
         else if (w < 29) { if (om3) om3[b * 3 + (w - 26)] = v; }
@@ -805,30 +948,44 @@ __global__ void unpack_state_kernel(int64_t B, const T* xs, const T* Ppk, T* x26
 // host-side launchers
 // ----------------------------------------------------------------------------------
 template <typename T, int LPI>
-static hipError_t launch_step_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
     const int64_t blocks = (a.B + G - 1) / G;
-    if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((eskf_step_kernel<T, LPI>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+    hipLaunchKernelGGL((eskf_cov_kernel<T, LPI>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
     return hipGetLastError();
 }
 
 template <typename T>
-static hipError_t launch_step_lpi(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+    if (a.B <= 0) return hipSuccess;
+    const unsigned sblocks = (unsigned)((a.B + 255) / 256);
+    // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
+    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3(sblocks), dim3(256), 0, stream, a, prm);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // 2. covariance: LPI lanes per instance
     switch (lpi) {
-        case 64: return launch_step_t<T, 64>(a, prm, stream);
-        case 32: return launch_step_t<T, 32>(a, prm, stream);
-        case 16: return launch_step_t<T, 16>(a, prm, stream);
-        case 12: return launch_step_t<T, 12>(a, prm, stream);
-        case 8:  return launch_step_t<T, 8>(a, prm, stream);
+        case 64: e = launch_cov_t<T, 64>(a, prm, stream); break;
+        case 32: e = launch_cov_t<T, 32>(a, prm, stream); break;
+        case 24: e = launch_cov_t<T, 24>(a, prm, stream); break;
+        case 16: e = launch_cov_t<T, 16>(a, prm, stream); break;
+        case 12: e = launch_cov_t<T, 12>(a, prm, stream); break;
+        case 8:  e = launch_cov_t<T, 8>(a, prm, stream); break;
         default: return hipErrorInvalidValue;
     }
+    if (e != hipSuccess) return e;
+    // 3. lane-per-instance: error injection
+    if (a.do_update) {
+        hipLaunchKernelGGL(eskf_post_kernel<T>, dim3(sblocks), dim3(256), 0, stream, a, prm);
+        e = hipGetLastError();
+    }
+    return e;
 }
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
-    if (dtype == 0) return launch_step_lpi<double>(lpi, a, make_dev_params<double>(hp), stream);
-    return launch_step_lpi<float>(lpi, a, make_dev_params<float>(hp), stream);
+    if (dtype == 0) return launch_step_typed<double>(lpi, a, make_dev_params<double>(hp), stream);
+    return launch_step_typed<float>(lpi, a, make_dev_params<float>(hp), stream);
 }
 
 hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,

@@ -124,13 +124,13 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_per_instance,
 int dvi_eskf_get_calibration(const dvi_eskf* h, void* dofs_out, void* stream);
 
 /* Raw device buffers (zero-copy views for profiling / checkpointing): packed lower
- * triangle of P [B,300] and the persistent state block [B,36] =
- * x26 | om_old3 | acc_old3 | q_old4. */
+ * triangle of P [B,300] and the persistent state block, structure-of-arrays [36,B] with
+ * words x26 | om_old3 | acc_old3 | q_old4. */
 void* dvi_eskf_raw_P(dvi_eskf* h);
 void* dvi_eskf_raw_x(dvi_eskf* h);
 
 /* Kernel variant selector for experiments: lanes per filter instance (64 = one
- * wavefront per instance; 12 = five instances per wavefront, the default). */
+ * wavefront per instance; 32 (default: two instances per wavefront), 24, 16, 12, 8). */
 int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes);
 
 const char* dvi_eskf_strerror(int code);

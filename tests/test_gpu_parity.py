@@ -224,7 +224,7 @@ def test_per_instance_inputs_match_broadcast():
         assert torch.equal(a[key], b[key]), key
 
 
-@pytest.mark.parametrize("lpi", [64, 32, 16, 8])
+@pytest.mark.parametrize("lpi", [64, 24, 16, 12, 8])
 def test_lane_layout_variants_agree(lpi):
     """The lanes-per-instance layouts run the same arithmetic per element."""
     B = 23   # ragged: not a multiple of any instances-per-wave count
