@@ -109,6 +109,7 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     a.dt_stride = dt_pi ? 1 : 0;
     a.imu_stride = imu_pi ? 1 : 0;
     a.meas_stride = meas_pi ? 1 : 0;
+    a.rounds = 1;
     hipError_t e = eskf::launch_step(h->dtype, h->lpi, a, h->hp, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }

@@ -68,6 +68,7 @@ struct StepArgs {
     int n_pred;
     int do_update;
     int dt_stride, imu_stride, meas_stride;
+    int rounds;         // instances per wave slot in the covariance kernel (set by the launcher)
 };
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);

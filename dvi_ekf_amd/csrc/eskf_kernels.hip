@@ -509,9 +509,10 @@ __global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T>
 // ----------------------------------------------------------------------------------
 constexpr int PS = 25;             // row stride of P
 constexpr int OFF_P = 0;           // 24 x 25
-constexpr int OFF_S = 600;         // scratch: U 6x24 (predict) | Z 24x7 (update)
-constexpr int OFF_J = 768;         // Jacobian record of the current predict (85 words) | L, 1/D, res (update)
-constexpr int OFF_E = 856;         // 24 error-state words
+constexpr int ZS = 8;              // row stride of the Z panel (16-byte aligned rows)
+constexpr int OFF_S = 600;         // scratch: U 6x24 (predict) | Z 24x8 (update)
+constexpr int OFF_J = 792;         // Jacobian record of the current predict (85 words, predict) |
+constexpr int OFF_E = 792;         //   24 error-state words (update; the record is dead by then)
 constexpr int REGION_MIN = 880;
 // regions of the instances sharing a wave are staggered so that their windows fall on
 // different banks: REGION = LPI (mod 32) (conflict-free for the 8-byte accesses below)
@@ -542,60 +543,76 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
     const int lane = threadIdx.x;
     const int grp = lane / LPI;
     const int lig = lane - grp * LPI;
-    const int64_t inst = (int64_t)blockIdx.x * G + grp;
-    if (grp >= G || inst >= a.B) return;   // idle lanes / tail instances: whole group leaves together
+    if (grp >= G) return;                   // lanes beyond the last whole instance slot idle
 
     T* sP = smem + grp * REGION + OFF_P;
     T* sS = smem + grp * REGION + OFF_S;
     T* sJ = smem + grp * REGION + OFF_J;
     T* sE = smem + grp * REGION + OFF_E;
-    T* gP = reinterpret_cast<T*>(a.P) + inst * 300;
 
     const int jwords = prm.q_gyro ? J_FULL : J_CORE;
     constexpr int NJ = (J_FULL + LPI - 1) / LPI;     // Jacobian words per lane (upper bound)
+    constexpr int NV = (150 + LPI - 1) / LPI;        // 16-byte (2-word) pieces of packed P per lane
+    using T2 = typename Vec2<T>::type;
 
-    // ---- load: packed P -> full symmetric LDS image.  All global loads are issued before the
-    // first LDS write so that their latencies overlap (one HBM round trip per wave, not one
-    // per element).
+    // A wave works through a.rounds instances per slot, one after the other.  The packed
+    // covariance and the first Jacobian record of round r+1 are fetched into registers while
+    // round r computes, so only the very first HBM round trip of a wave is exposed.
+    const int64_t round_stride = (int64_t)gridDim.x * G;
+    const int64_t slot = (int64_t)blockIdx.x * G + grp;
+    T2 pv[NV];
+    T jv[NJ];
+#define ESKF_ISSUE_LOADS(INST)                                                                     \
+    {                                                                                              \
+        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P) + (INST) * 300); \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
+            const int e2 = lig + k * LPI;                                                          \
+            if (e2 < 150) pv[k] = gP2_[e2];                                                        \
+        }                                                                                          \
+        if (a.n_pred > 0) {                                                                        \
+            const T* gJ_ = reinterpret_cast<const T*>(a.J) + (INST) * JW;                          \
+            _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                       \
+                const int e = lig + k * LPI;                                                       \
+                if (e < jwords) jv[k] = gJ_[e];                                                    \
+            }                                                                                      \
+        }                                                                                          \
+    }
     {
-        using T2 = typename Vec2<T>::type;
-        constexpr int NV = (150 + LPI - 1) / LPI;    // 16-byte (2-word) pieces per lane
-        const T2* gP2 = reinterpret_cast<const T2*>(gP);
-        T2 v[NV];
-        T jv[NJ];
+        const int64_t i0 = slot < a.B ? slot : a.B - 1;
+        ESKF_ISSUE_LOADS(i0)
+    }
+
+  for (int rnd = 0; rnd < a.rounds; ++rnd) {
+    const int64_t inst_raw = (int64_t)rnd * round_stride + slot;
+    const bool valid = inst_raw < a.B;      // tail: recompute the last instance, write nothing
+    const int64_t inst = valid ? inst_raw : a.B - 1;
+    T* gP = reinterpret_cast<T*>(a.P) + inst * 300;
+
+    // ---- packed P (registers) -> full symmetric LDS image; Jacobian record -> LDS ------------
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int e2 = lig + k * LPI;
-            if (e2 < 150) v[k] = gP2[e2];
+    for (int k = 0; k < NV; ++k) {
+        const int e2 = lig + k * LPI;
+        if (e2 < 150) {
+            int i, j;
+            unpack_ij(2 * e2, i, j);
+            sP[i * PS + j] = pv[k].x;
+            sP[j * PS + i] = pv[k].x;
+            unpack_ij(2 * e2 + 1, i, j);
+            sP[i * PS + j] = pv[k].y;
+            sP[j * PS + i] = pv[k].y;
         }
-        if (a.n_pred > 0) {
-            const T* gJ = reinterpret_cast<const T*>(a.J) + inst * JW;
+    }
+    if (a.n_pred > 0) {
 #pragma unroll
-            for (int k = 0; k < NJ; ++k) {
-                const int e = lig + k * LPI;
-                if (e < jwords) jv[k] = gJ[e];
-            }
+        for (int k = 0; k < NJ; ++k) {
+            const int e = lig + k * LPI;
+            if (e < jwords) sJ[e] = jv[k];
         }
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int e2 = lig + k * LPI;
-            if (e2 < 150) {
-                int i, j;
-                unpack_ij(2 * e2, i, j);
-                sP[i * PS + j] = v[k].x;
-                sP[j * PS + i] = v[k].x;
-                unpack_ij(2 * e2 + 1, i, j);
-                sP[i * PS + j] = v[k].y;
-                sP[j * PS + i] = v[k].y;
-            }
-        }
-        if (a.n_pred > 0) {
-#pragma unroll
-            for (int k = 0; k < NJ; ++k) {
-                const int e = lig + k * LPI;
-                if (e < jwords) sJ[e] = jv[k];
-            }
-        }
+    }
+    if (rnd + 1 < a.rounds) {               // prefetch the next round's instance
+        const int64_t nraw = (int64_t)(rnd + 1) * round_stride + slot;
+        const int64_t ni = nraw < a.B ? nraw : a.B - 1;
+        ESKF_ISSUE_LOADS(ni)
     }
 
     // ================================ predict(s) =======================================
@@ -660,9 +677,10 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
         }
         group_sync();
 
-        // ---- phase 2: lane owns a row.  Rows 0..17: column operations of Faa^T plus the
-        // diagonal of Fi Q Fi^T.  Rows 18..23 (owner of U row a): P'cc = U Fc^T, P'ca = U
-        // Faa^T, camera part of Fi Q Fi^T; written to row 18+a and mirrored into column 18+a.
+        // ---- phase 2: lane owns a row.  Items 0..17: column operations of Faa^T on row i plus
+        // the diagonal of Fi Q Fi^T, and two entries of P'cc = U Fx[18:24,:]^T (the 36 entries
+        // are spread over these 18 lanes).  Items 18..23 (U row a): P'ca = U Faa^T, written to
+        // row 18+a and mirrored into column 18+a.
         for (int it = lig; it < 24; it += LPI) {
             if (it < 18) {
                 const int i = it;
@@ -690,30 +708,37 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                     qi = (i == 17) ? prm.qd[12] : qi;
                     if (i >= 3) sP[i * PS + i] += qi;
                 }
+                // P'cc[a2][b2] and P'cc[a2][3 + b2]
+                const int a2 = it / 3, b2 = it - 3 * a2;
+                const T* u = sS + a2 * 24;
+                T x = dt * u[3 + b2] + u[16 + b2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) x += Bm[3 * b2 + k] * u[6 + k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) x += Cm[6 * b2 + k] * u[9 + k];
+                T y = Dm[4 * b2 + 3] * u[15];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) y += Dm[4 * b2 + k] * u[9 + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) y += Em[3 * b2 + k] * u[19 + k];
+                if (b2 >= 1) y += u[21 + b2];   // the (22,22) and (23,23) ones of the identity survive
+                if (prm.q_gyro) {   // camera block of Fi Q Fi^T (gyro noise enters rows 18:24 through N6)
+                    const T* N6 = sJ + J_N6;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T nk = N6[3 * a2 + k] * prm.qd[3 + k];
+                        x += nk * N6[3 * b2 + k];
+                        y += nk * N6[3 * (3 + b2) + k];
+                    }
+                }
+                sP[(18 + a2) * PS + 18 + b2] = x;
+                sP[(18 + a2) * PS + 21 + b2] = y;
             } else {
                 const int ar = it - 18;
-                T u[24];
+                T u[18];
 #pragma unroll
-                for (int k = 0; k < 24; ++k) u[k] = sS[ar * 24 + k];
-                T row[24];
-                // P'cc[ar][b]
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    T x = dt * u[3 + b] + u[16 + b];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) x += Bm[3 * b + k] * u[6 + k];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) x += Cm[6 * b + k] * u[9 + k];
-                    row[18 + b] = x;
-                    T y = Dm[4 * b + 3] * u[15];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) y += Dm[4 * b + k] * u[9 + k];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) y += Em[3 * b + k] * u[19 + k];
-                    if (b == 1) y += u[22];
-                    if (b == 2) y += u[23];
-                    row[21 + b] = y;
-                }
+                for (int k = 0; k < 18; ++k) u[k] = sS[ar * 24 + k];
+                T row[18];
                 // P'ca[ar][0:18] = U[ar][0:18] Faa^T
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
@@ -728,20 +753,14 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 row[17] = u[17];
                 if (prm.q_gyro) {   // Fi[6:9,3:6] = I couples the gyro noise into the camera rows
                     const T* N6 = sJ + J_N6;
-                    T nr[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        nr[k] = N6[3 * ar + k] * prm.qd[3 + k];
-                        row[6 + k] += nr[k];
-                    }
-#pragma unroll
-                    for (int b = 0; b < 6; ++b)
-                        row[18 + b] += nr[0] * N6[3 * b] + nr[1] * N6[3 * b + 1] + nr[2] * N6[3 * b + 2];
+                    for (int k = 0; k < 3; ++k) row[6 + k] += N6[3 * ar + k] * prm.qd[3 + k];
                 }
 #pragma unroll
-                for (int k = 0; k < 24; ++k) sP[(18 + ar) * PS + k] = row[k];
-#pragma unroll
-                for (int k = 0; k < 18; ++k) sP[k * PS + 18 + ar] = row[k];
+                for (int k = 0; k < 18; ++k) {
+                    sP[(18 + ar) * PS + k] = row[k];
+                    sP[k * PS + 18 + ar] = row[k];
+                }
             }
         }
         group_sync();
@@ -804,11 +823,11 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 }
                 T e = T(0);
 #pragma unroll
-                for (int m = 0; m < 7; ++m) { e += k[m] * res[m]; sS[i * 7 + m] = z[m]; }
+                for (int m = 0; m < 7; ++m) { e += k[m] * res[m]; sS[i * ZS + m] = z[m]; }
                 if (i >= 9 && i < 15 && ((prm.frozen_mask >> (i - 9)) & 1)) e = T(0);   // Filter.py:377-379
                 sE[i] = e;
-                reinterpret_cast<T*>(a.e)[inst * 24 + i] = e;
-                if (a.K_out) {
+                if (valid) reinterpret_cast<T*>(a.e)[inst * 24 + i] = e;
+                if (a.K_out && valid) {
                     T* gK = reinterpret_cast<T*>(a.K_out) + (inst * 24 + i) * 7;
 #pragma unroll
                     for (int m = 0; m < 7; ++m) gK[m] = k[m];
@@ -817,43 +836,49 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
         }
         group_sync();
         if (ok) {
-            // half error angles of the reset Jacobian (Filter.py:387-390)
-            const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
-            const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
-
-            // ---- phase 4: lane owns column j.  P[:,j] -= Z (D^-1 Z[j,:]^T)  (Joseph form with the
-            // optimal gain, Filter.py:383-384), then the row part of the reset G P G^T on its column.
+            // ---- phase 4: P -= Z D^-1 Z^T (Joseph form with the optimal gain, Filter.py:383-384),
+            // lower triangle only: lane j updates the 13 (12 for j >= 12) elements (j+d mod 24, j),
+            // d = 0..12 -- every unordered pair exactly once -- and writes both mirror positions.
             for (int j = lig; j < 24; j += LPI) {
                 T zd[7];
 #pragma unroll
-                for (int m = 0; m < 7; ++m) zd[m] = sS[j * 7 + m] * rd[m];
-                T c[24];
+                for (int m = 0; m < 7; ++m) zd[m] = sS[j * ZS + m] * rd[m];
+                const int nd = (j < 12) ? 13 : 12;
 #pragma unroll
-                for (int i = 0; i < 24; ++i) {
-                    T v = sP[i * PS + j];
+                for (int dd = 0; dd < 13; ++dd) {
+                    if (dd < nd) {
+                        int i = j + dd;
+                        if (i >= 24) i -= 24;
+                        const T* zi = sS + i * ZS;
+                        T v = sP[i * PS + j];
 #pragma unroll
-                    for (int m = 0; m < 7; ++m) v -= sS[i * 7 + m] * zd[m];
-                    c[i] = v;
+                        for (int m = 0; m < 7; ++m) v -= zi[m] * zd[m];
+                        sP[i * PS + j] = v;
+                        sP[j * PS + i] = v;
+                    }
                 }
-                {
-                    const T a0 = c[6], a1 = c[7], a2 = c[8];
-                    c[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
-                    c[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
-                    c[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
-                    const T b0 = c[21], b1 = c[22], b2 = c[23];
-                    c[21] = b0 + Gc[2] * b1 - Gc[1] * b2;
-                    c[22] = b1 - Gc[2] * b0 + Gc[0] * b2;
-                    c[23] = b2 + Gc[1] * b0 - Gc[0] * b1;
-                }
-#pragma unroll
-                for (int i = 0; i < 24; ++i) sP[i * PS + j] = c[i];
+            }
+        }
+        group_sync();
+        // half error angles of the reset Jacobian G = I - [theta/2]x blocks (Filter.py:387-390)
+        const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
+        const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
+        if (ok) {
+            // ---- phase 5a: lane owns column j: rows 6:9 and 21:24 of G P
+            for (int j = lig; j < 24; j += LPI) {
+                const T a0 = sP[6 * PS + j], a1 = sP[7 * PS + j], a2 = sP[8 * PS + j];
+                sP[6 * PS + j] = a0 + Gt[2] * a1 - Gt[1] * a2;
+                sP[7 * PS + j] = a1 - Gt[2] * a0 + Gt[0] * a2;
+                sP[8 * PS + j] = a2 + Gt[1] * a0 - Gt[0] * a1;
+                const T b0 = sP[21 * PS + j], b1 = sP[22 * PS + j], b2 = sP[23 * PS + j];
+                sP[21 * PS + j] = b0 + Gc[2] * b1 - Gc[1] * b2;
+                sP[22 * PS + j] = b1 - Gc[2] * b0 + Gc[0] * b2;
+                sP[23 * PS + j] = b2 + Gc[1] * b0 - Gc[0] * b1;
             }
         }
         group_sync();
         if (ok) {
-            const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
-            const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
-            // ---- phase 5: lane owns row i: column part of the reset.
+            // ---- phase 5b: lane owns row i: columns 6:9 and 21:24 of (G P) G^T
             for (int i = lig; i < 24; i += LPI) {
                 const T a0 = sP[i * PS + 6], a1 = sP[i * PS + 7], a2 = sP[i * PS + 8];
                 sP[i * PS + 6] = a0 + Gt[2] * a1 - Gt[1] * a2;
@@ -866,13 +891,11 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
             }
         }
         group_sync();
-        if (lig == 0) a.status_ws[inst] = status;
+        if (lig == 0 && valid) a.status_ws[inst] = status;
     }
 
     // ---- store: lower triangle -> packed record (16-byte stores) --------------------------
-    {
-        using T2 = typename Vec2<T>::type;
-        constexpr int NV = (150 + LPI - 1) / LPI;
+    if (valid) {
         T2* gP2 = reinterpret_cast<T2*>(gP);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
@@ -888,8 +911,10 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
             }
         }
     }
+    group_sync();   // the next round overwrites the LDS image
+  }
+#undef ESKF_ISSUE_LOADS
 }
-
 
 // ----------------------------------------------------------------------------------
 // state import / export between the user-facing layout and the device records
@@ -950,9 +975,16 @@ __global__ void unpack_state_kernel(int64_t B, const T* xs, const T* Ppk, T* x26
 template <typename T, int LPI>
 static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
-    const int64_t blocks = (a.B + G - 1) / G;
+    // rounds per wave: enough waves to keep every CU's LDS full several times over, few enough
+    // that most HBM round trips hide behind the previous instance's arithmetic
+    StepArgs b = a;
+    int64_t blocks = (a.B + G - 1) / G;
+    int rounds = 1;
+    while (rounds < 4 && blocks / (rounds * 2) >= 256 * 16) rounds *= 2;
+    b.rounds = rounds;
+    blocks = (a.B + (int64_t)G * rounds - 1) / ((int64_t)G * rounds);
     if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((eskf_cov_kernel<T, LPI>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+    hipLaunchKernelGGL((eskf_cov_kernel<T, LPI>), dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
     return hipGetLastError();
 }
 
