@@ -16,14 +16,20 @@ with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
 trace = glob.glob(os.path.join(kdir, "**", "*_kernel_trace.csv"), recursive=True)
 res = {"tag": tag}
 if trace:
-    t = [r for r in csv.DictReader(open(trace[0])) if "eskf_step_kernel" in r["Kernel_Name"]]
-    if t:
+    allrows = list(csv.DictReader(open(trace[0])))
+    res["step_kernels"] = {}
+    for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_post_kernel"):
+        t = [r for r in allrows if key in r["Kernel_Name"]]
+        if not t:
+            continue
         r0 = t[0]
-        res["step_kernel"] = {k: r0.get(k) for k in ("Kernel_Name", "Workgroup_Size", "Grid_Size", "LDS_Block_Size",
-                                                      "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
+        info = {k: r0.get(k) for k in ("Kernel_Name", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
+                                         "Accum_VGPR_Count", "SGPR_Count")}
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in t]
-        res["step_kernel"]["launches"] = len(d)
-        res["step_kernel"]["avg_ns"] = sum(d) / len(d)
+        info["launches"] = len(d)
+        info["avg_ns"] = sum(d) / len(d)
+        res["step_kernels"][key] = info
+    res["step_avg_ns_sum_of_kernels"] = sum(v["avg_ns"] for v in res["step_kernels"].values())
 if len(sys.argv) >= 5:
     pm = {}
     calib = {}
@@ -32,9 +38,11 @@ if len(sys.argv) >= 5:
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(fn)):
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        pm[name] = {}
         for k, v in acc.items():
-            if "eskf_step_kernel" in k:
-                pm[name] = {"launches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}
+            for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_post_kernel"):
+                if key in k:
+                    pm[name][key] = {"launches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}
             if "copyBuffer" in k:
                 calib[name] = max(v)
     res["pmc_step_kernel"] = pm
@@ -43,9 +51,9 @@ if len(sys.argv) >= 5:
         # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced
         # streaming read (calibrated in the same run on the runtime's copyBuffer of known size);
         # WRITE_SIZE is exact.  Units are KiB.
-        rd = pm["FETCH_SIZE"]["mean_KiB"] * 1024 * 2
-        wr = pm["WRITE_SIZE"]["mean_KiB"] * 1024
-        res["hbm_bytes_per_launch"] = rd + wr
+        rd = sum(v["mean_KiB"] for v in pm["FETCH_SIZE"].values()) * 1024 * 2
+        wr = sum(v["mean_KiB"] for v in pm["WRITE_SIZE"].values()) * 1024
+        res["hbm_bytes_per_launch"] = rd + wr   # per step: all kernels of one predict+update pair
         res["hbm_read_bytes_per_launch_corrected_x2"] = rd
         res["hbm_write_bytes_per_launch"] = wr
 json.dump(res, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
