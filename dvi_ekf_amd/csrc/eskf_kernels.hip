@@ -194,48 +194,54 @@ struct Jac {
 // + State.from_array (state.py:62-74), then the Jacobian blocks of Filter._predict_error /
 // _cam_error_jacobian (Filter.py:249-342) evaluated -- as the reference does -- at the
 // post-step dofs/notch with the pre-step buffers om_old, acc_old, R_WB_old.
-template <typename T>
+// NOMINAL = false: only what the Jacobians of the following steps depend on is advanced
+// (attitude q, dofs, notch); JAC = false: the blocks are not formed.  The two halves are
+// independent, so the pre kernel gives them to different waves.
+template <typename T, bool NOMINAL = true, bool JAC = true>
 __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& prm, T dt, const T* om_n,
                                                const T* acc_n, Jac<T>& J) {
-    T R[9], Rc[9], Ro[9];
+    T R[9], Ro[9];
     quat_to_mat(s.q, R);
-    quat_to_mat(s.qc, Rc);
-    quat_to_mat(s.qo, Ro);
+    if (JAC) quat_to_mat(s.qo, Ro);
 
     // --- nominal state -------------------------------------------------------------
     {
-        const ProbeTrig<T> t = probe_trig(s.dofs, s.notch[0]);
-        T pB[3], RBC[9], z6[3];
-        probe_pose(t, s.dofs, prm.L, prm.st, prm.ct, pB, RBC, z6);
-
         T om_avg[3], w[3], RS[9], Rn[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { om_avg[i] = (s.om_o[i] + om_n[i]) * T(0.5); w[i] = dt * om_avg[i]; }
         mat3_skew(R, w, RS);
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rn[i] = R[i] + RS[i];                           // equations.py:46
-        T a1[3], a2[3], acc_avg[3];
-        mat3_vec(R, s.acc_o, a1);
-        mat3_vec(Rn, acc_n, a2);
+        if (NOMINAL) {
+            T Rc[9];
+            quat_to_mat(s.qc, Rc);
+            const ProbeTrig<T> t = probe_trig(s.dofs, s.notch[0]);
+            T pB[3], RBC[9], z6[3];
+            probe_pose(t, s.dofs, prm.L, prm.st, prm.ct, pB, RBC, z6);
+            T a1[3], a2[3], acc_avg[3];
+            mat3_vec(R, s.acc_o, a1);
+            mat3_vec(Rn, acc_n, a2);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);          // equations.py:47
-        T u[3], C_om[3], cr[3], Rcr[3], wc[3], RcS[9], Rcn[9];
+            for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);      // equations.py:47
+            T u[3], C_om[3], cr[3], Rcr[3], wc[3], RcS[9], Rcn[9];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) u[i] = s.om_o[i] + z6[i] * s.notch[1];
-        mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
-        cross3(om_avg, pB, cr);                                                     // BB_v_CB == 0
-        mat3_vec(R, cr, Rcr);
+            for (int i = 0; i < 3; ++i) u[i] = s.om_o[i] + z6[i] * s.notch[1];
+            mat3T_vec(RBC, u, C_om);                                                // equations.py:50
+            cross3(om_avg, pB, cr);                                                 // BB_v_CB == 0
+            mat3_vec(R, cr, Rcr);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const T vi = s.v[i];
-            s.p[i] = s.p[i] + dt * vi + (dt * dt * T(0.5)) * acc_avg[i];            // equations.py:76
-            s.v[i] = vi + dt * acc_avg[i];                                          // equations.py:77
-            s.pc[i] = s.pc[i] + dt * vi + dt * Rcr[i];                              // equations.py:83-85
-            wc[i] = dt * C_om[i];
+            for (int i = 0; i < 3; ++i) {
+                const T vi = s.v[i];
+                s.p[i] = s.p[i] + dt * vi + (dt * dt * T(0.5)) * acc_avg[i];        // equations.py:76
+                s.v[i] = vi + dt * acc_avg[i];                                      // equations.py:77
+                s.pc[i] = s.pc[i] + dt * vi + dt * Rcr[i];                          // equations.py:83-85
+                wc[i] = dt * C_om[i];
+            }
+            mat3_skew(Rc, wc, RcS);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rcn[i] = Rc[i] + RcS[i];                    // equations.py:86
+            mat_to_quat(Rcn, s.qc);                                                 // state.py:72
         }
-        mat3_skew(Rc, wc, RcS);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rcn[i] = Rc[i] + RcS[i];                        // equations.py:86
         s.notch[0] += dt * s.notch[1];                                              // equations.py:80-82
         s.notch[1] += dt * s.notch[2];
         if (!prm.hold_frozen) {                                                     // Filter.py:243-245
@@ -244,7 +250,13 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
                 if ((prm.frozen_mask >> i) & 1) s.dofs[i] = T(0);
         }
         mat_to_quat(Rn, s.q);                                                       // state.py:67
-        mat_to_quat(Rcn, s.qc);                                                     // state.py:72
+    }
+    if (!JAC) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s.om_o[i] = om_n[i]; s.acc_o[i] = acc_n[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s.qo[i] = s.q[i];
+        return;
     }
 
     // --- Jacobian blocks -----------------------------------------------------------
@@ -422,7 +434,9 @@ __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const S
     for (int i = 0; i < 6; ++i) xs[(10 + i) * B + b] = s.dofs[i];
 }
 
-// ---- lane-per-instance: nominal propagation + Jacobian blocks + residual ---------------------
+// ---- lane-per-instance: nominal propagation + residual (blockIdx.y = 0) and Jacobian blocks
+// (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
+// different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
 template <typename T>
 __global__ __launch_bounds__(256) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -430,6 +444,8 @@ __global__ __launch_bounds__(256) void eskf_pre_kernel(StepArgs a, DevParams<T> 
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
+    const bool jac_role = blockIdx.y != 0;
+    if (jac_role && a.n_pred == 0) return;
     for (int ip = 0; ip < a.n_pred; ++ip) {
         const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
         const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
@@ -438,9 +454,14 @@ __global__ __launch_bounds__(256) void eskf_pre_kernel(StepArgs a, DevParams<T> 
         const T dt = gdt[0];
         T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
         Jac<T> J;
-        predict_scalar(s, prm, dt, om_n, acc_n, J);
-        store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, prm.q_gyro != 0);
+        if (jac_role) {
+            predict_scalar<T, false, true>(s, prm, dt, om_n, acc_n, J);
+            store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, prm.q_gyro != 0);
+        } else {
+            predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
+        }
     }
+    if (jac_role) return;
     if (a.do_update) {
         // measurement correction and residual (Filter.py:364-375)
         const int64_t mo = a.meas_stride ? b : 0;
@@ -993,7 +1014,7 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (a.B <= 0) return hipSuccess;
     const unsigned sblocks = (unsigned)((a.B + 255) / 256);
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3(sblocks), dim3(256), 0, stream, a, prm);
+    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3(sblocks, 2), dim3(256), 0, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 2. covariance: LPI lanes per instance
