@@ -388,6 +388,10 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
 // The nominal state never reads P, so one pre-launch covers all n_pred predicts of an epoch
 // and the covariance kernel runs them back to back with P resident in LDS.
 // ----------------------------------------------------------------------------------
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
 constexpr int JW = 88;          // words per Jacobian record: A9 Th9 Bm9 Cm18 Dm12 Em9 dt1 | N6 18 | pad
 constexpr int J_A = 0, J_TH = 9, J_BM = 18, J_CM = 27, J_DM = 45, J_EM = 57, J_DT = 66, J_N6 = 67;
 constexpr int J_CORE = 67, J_FULL = 85;
@@ -438,14 +442,23 @@ __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const S
 // (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
 template <typename T>
-__global__ __launch_bounds__(256) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+__global__ __launch_bounds__(64) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
+    // one wavefront per block.  The Jacobian role stages its 67-word records in LDS (row stride 69:
+    // conflict-free) and writes them out as whole records with 16-byte stores -- a lane-per-instance
+    // store of an array-of-structures would touch 64 different cache lines per instruction.
+    constexpr int JS = 69;
+    __shared__ __attribute__((aligned(16))) T sJ[64 * JS];
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int64_t b_raw = b0 + lane;
+    const bool live = b_raw < a.B;
+    const int64_t b = live ? b_raw : a.B - 1;      // tail lanes recompute the last instance, write nothing
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
     const bool jac_role = blockIdx.y != 0;
     if (jac_role && a.n_pred == 0) return;
+    const int jwords = prm.q_gyro ? J_FULL : J_CORE;
     for (int ip = 0; ip < a.n_pred; ++ip) {
         const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
         const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
@@ -456,12 +469,31 @@ __global__ __launch_bounds__(256) void eskf_pre_kernel(StepArgs a, DevParams<T> 
         Jac<T> J;
         if (jac_role) {
             predict_scalar<T, false, true>(s, prm, dt, om_n, acc_n, J);
-            store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, prm.q_gyro != 0);
+            if (prm.q_gyro) {       // 85-word records do not fit the staging rows: direct stores
+                if (live) store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, true);
+            } else {
+                store_jac(J, sJ + lane * JS, false);
+                __syncthreads();
+                T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
+                const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
+                // record r: words [0, 67) -> 34 pieces of 2 words (the last piece carries one pad word)
+                for (int r = 0; r < nrec; ++r) {
+                    if (lane < 34) {
+                        using T2 = typename Vec2<T>::type;
+                        T2 v;
+                        v.x = sJ[r * JS + 2 * lane];
+                        v.y = sJ[r * JS + 2 * lane + 1];
+                        reinterpret_cast<T2*>(gJ + (int64_t)r * JW)[lane] = v;
+                    }
+                }
+                __syncthreads();
+            }
         } else {
             predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
         }
     }
-    if (jac_role) return;
+    (void)jwords;
+    if (jac_role || !live) return;
     if (a.do_update) {
         // measurement correction and residual (Filter.py:364-375)
         const int64_t mo = a.meas_stride ? b : 0;
@@ -545,9 +577,6 @@ __host__ __device__ constexpr int region_words(int lpi) {
 
 __device__ __forceinline__ void group_sync() { __syncthreads(); }   // block == one wavefront
 
-template <typename T> struct Vec2;
-template <> struct Vec2<double> { using type = double2; };
-template <> struct Vec2<float> { using type = float2; };
 
 // packed index -> (i, j), i >= j
 __device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
@@ -1014,7 +1043,7 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (a.B <= 0) return hipSuccess;
     const unsigned sblocks = (unsigned)((a.B + 255) / 256);
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3(sblocks, 2), dim3(256), 0, stream, a, prm);
+    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64), 2), dim3(64), 0, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 2. covariance: LPI lanes per instance

@@ -1,0 +1,123 @@
+"""BASELINE.json configurations at their full sizes, through size-independent properties,
+plus sampled comparisons with the oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle
+from tests.helpers import default_run
+
+
+def _filter(cfg, Q, R, sa, so, B, hold, dtype=torch.float64):
+    from dvi_ekf_amd.batch import BatchedESKF
+    f = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=cfg.frozen_dofs, sigma_a=sa,
+                    sigma_om=so, hold_frozen=hold, dtype=dtype)
+    f.set_noise(Q, R)
+    return f
+
+
+def test_config2_and_4_full_batch_identical_instances_and_symmetry():
+    """B = 65 536 (config #4 size) with identical inputs: every instance must equal instance 0 bit
+    for bit (no cross-talk between the instances of a wavefront / tail handling), instance 0 must
+    follow the oracle, and P must stay symmetric positive semi-definite on the sane horizon."""
+    B = 65536
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=False, frozen=(1,) * 6, interframe=1)
+    f = _filter(cfg, Q, R, sa, so, B, True)
+    f.set_state(x=ri.x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, True, sa, so, Q, R)
+    o = c_oracle.OracleBatch(prm, ri.x0[None, :], ri.P0, ri.om0, ri.acc0)
+    for k in range(12):
+        st, _ = f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
+        o.predict(ri.dt[k], ri.om[k], ri.acc[k])
+        o.update(ri.pos[k], ri.quat[k], ri.notch[k])
+    assert int(st.abs().max()) == 0
+    x = f.x
+    assert bool((x == x[0:1]).all())
+    raw = f.get_state(("P",))["P"]
+    assert bool((raw == raw[0:1]).all())
+    assert np.abs(x[0].cpu().numpy() - o.x[0]).max() <= 1e-9
+    P0 = raw[0].cpu().numpy()
+    assert np.array_equal(P0, P0.T)
+    assert np.linalg.eigvalsh(P0).min() > -1e-9 * np.abs(P0).max()
+
+
+def test_config2_batch1024_perturbed_instances_vs_oracle():
+    """config #2: B = 1024, fp64, 1:1 pairs; instance 0 = the reference run, the others start from
+    perturbed extrinsic DOFs (unfrozen); 8 pair-steps free-running; all 1024 instances vs oracle."""
+    B = 1024
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=False, frozen=(0,) * 6, interframe=1)
+    rng = np.random.default_rng(1000)
+    x0 = np.tile(ri.x0, (B, 1))
+    x0[1:, 10:16] += rng.normal(0, 1, (B - 1, 6)) * np.sqrt(np.diag(ri.P0)[9:15])
+    f = _filter(cfg, Q, R, sa, so, B, True)
+    f.set_state(x=x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, True, sa, so, Q, R)
+    o = c_oracle.OracleBatch(prm, x0, ri.P0, ri.om0, ri.acc0)
+    for k in range(8):
+        f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
+        o.predict(ri.dt[k], ri.om[k], ri.acc[k])
+        o.update(ri.pos[k], ri.quat[k], ri.notch[k])
+    x = f.x.cpu().numpy()
+    err = np.abs(x - o.x).max(axis=1)
+    scale = np.maximum(1.0, np.abs(o.x).max(axis=1))
+    print(f"config #2: max|dx| over 1024 instances after 8 pairs = {err.max():.2e} (median {np.median(err):.1e})")
+    assert (err / scale).max() <= 1e-9
+
+
+def test_config3_predict_only_fp32_one_million_instances():
+    """config #3: predict-only, B = 1 048 576, fp32, dt = 1e-3, random IMU samples.  Properties:
+    finite, P symmetric, trace grows by the random-walk variance only; 64 sampled instances follow
+    the fp64 oracle to fp32 accuracy (stated tolerance: 1e-4 relative on x, 1e-3 on P)."""
+    B = 1 << 20
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    f = _filter(cfg, Q, R, sa, so, B, False, dtype=torch.float32)
+    f.set_state(x=ri.x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, False, sa, so, Q, R)
+    sample = np.linspace(0, B - 1, 64).astype(np.int64)
+    o = c_oracle.OracleBatch(prm, np.tile(ri.x0, (64, 1)), ri.P0, ri.om0, ri.acc0)
+    for _ in range(4):
+        om = torch.randn((B, 3), generator=g, device="cuda", dtype=torch.float32) * 0.05
+        acc = torch.randn((B, 3), generator=g, device="cuda", dtype=torch.float32)
+        f.predict(1e-3, om, acc)
+        o.predict(1e-3, om[sample].double().cpu().numpy(), acc[sample].double().cpu().numpy())
+    st = f.get_state(("x", "P"))
+    assert bool(torch.isfinite(st["x"]).all()) and bool(torch.isfinite(st["P"]).all())
+    assert bool((st["P"] == st["P"].transpose(1, 2)).all())
+    xs, Ps = st["x"][sample].double().cpu().numpy(), st["P"][sample].double().cpu().numpy()
+    assert np.abs(xs - o.x).max() <= 1e-4 * np.abs(o.x).max()
+    assert np.abs(Ps - o.P).max() <= 1e-3 * np.abs(o.P).max()
+
+
+def test_config5_long_horizon_epochs_fp64_and_fp32():
+    """config #5 shape: epochs of 33/33/34 predicts (dt = 1e-3) + one update, B = 8192.  The fp64
+    run is compared with the oracle on 16 sampled instances for 6 epochs (200 predicts); the fp32
+    run must stay finite with status 0."""
+    B = 8192
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(1,) * 6)
+    rng = np.random.default_rng(5)
+    sample = np.linspace(0, B - 1, 16).astype(np.int64)
+    prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, False, sa, so, Q, R)
+    o = c_oracle.OracleBatch(prm, np.tile(ri.x0, (16, 1)), ri.P0, ri.om0, ri.acc0)
+    f64 = _filter(cfg, Q, R, sa, so, B, False)
+    f32 = _filter(cfg, Q, R, sa, so, B, False, dtype=torch.float32)
+    for f in (f64, f32):
+        f.set_state(x=ri.x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    for ep in range(6):
+        n = (33, 33, 34)[ep % 3]
+        dt = np.full(n, 1e-3)
+        om = ri.om[ep] + rng.normal(0, 1e-3, (n, 3))
+        acc = ri.acc[ep] + rng.normal(0, 1e-2, (n, 3))
+        s64, _ = f64.epoch(dt, om, acc, ri.pos[ep], ri.quat[ep], ri.notch[ep])
+        s32, _ = f32.epoch(dt, om, acc, ri.pos[ep], ri.quat[ep], ri.notch[ep])
+        for i in range(n):
+            o.predict(dt[i], om[i], acc[i])
+        o.update(ri.pos[ep], ri.quat[ep], ri.notch[ep])
+        assert int(s64.abs().max()) == 0 and int(s32.abs().max()) == 0
+    x64 = f64.x
+    assert bool((x64 == x64[0:1]).all())
+    assert np.abs(x64[sample].cpu().numpy() - o.x).max() <= 1e-9
+    assert bool(torch.isfinite(f32.x).all()) and bool(torch.isfinite(f32.P).all())
