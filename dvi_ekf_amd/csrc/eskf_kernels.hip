@@ -442,13 +442,16 @@ __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const S
 // (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
 template <typename T>
-__global__ __launch_bounds__(64) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
-    // one wavefront per block.  The Jacobian role stages its 67-word records in LDS (row stride 69:
+__global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
+    // Two wavefronts per block work on the same 64 instances: wave 0 propagates the nominal state
+    // (and forms the residual), wave 1 forms the Jacobian blocks.  Both read the state before wave 0
+    // overwrites it (block barrier).  Wave 1 stages its 67-word records in LDS (row stride 69:
     // conflict-free) and writes them out as whole records with 16-byte stores -- a lane-per-instance
     // store of an array-of-structures would touch 64 different cache lines per instruction.
     constexpr int JS = 69;
     __shared__ __attribute__((aligned(16))) T sJ[64 * JS];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool jac_role = threadIdx.x >= 64;           // wave-uniform
     const int64_t b0 = (int64_t)blockIdx.x * 64;
     const int64_t b_raw = b0 + lane;
     const bool live = b_raw < a.B;
@@ -456,9 +459,8 @@ __global__ __launch_bounds__(64) void eskf_pre_kernel(StepArgs a, DevParams<T> p
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
-    const bool jac_role = blockIdx.y != 0;
+    __syncthreads();                               // every read of the old state precedes its update
     if (jac_role && a.n_pred == 0) return;
-    const int jwords = prm.q_gyro ? J_FULL : J_CORE;
     for (int ip = 0; ip < a.n_pred; ++ip) {
         const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
         const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
@@ -472,8 +474,11 @@ __global__ __launch_bounds__(64) void eskf_pre_kernel(StepArgs a, DevParams<T> p
             if (prm.q_gyro) {       // 85-word records do not fit the staging rows: direct stores
                 if (live) store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, true);
             } else {
+                // only this wavefront touches sJ: wave-level ordering is enough
                 store_jac(J, sJ + lane * JS, false);
-                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
                 const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
                 // record r: words [0, 67) -> 34 pieces of 2 words (the last piece carries one pad word)
@@ -486,13 +491,14 @@ __global__ __launch_bounds__(64) void eskf_pre_kernel(StepArgs a, DevParams<T> p
                         reinterpret_cast<T2*>(gJ + (int64_t)r * JW)[lane] = v;
                     }
                 }
-                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         } else {
             predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
         }
     }
-    (void)jwords;
     if (jac_role || !live) return;
     if (a.do_update) {
         // measurement correction and residual (Filter.py:364-375)
@@ -1043,7 +1049,7 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (a.B <= 0) return hipSuccess;
     const unsigned sblocks = (unsigned)((a.B + 255) / 256);
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64), 2), dim3(64), 0, stream, a, prm);
+    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), 0, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 2. covariance: LPI lanes per instance
