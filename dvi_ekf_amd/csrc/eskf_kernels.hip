@@ -569,10 +569,11 @@ __global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T>
 constexpr int PS = 25;             // row stride of P
 constexpr int OFF_P = 0;           // 24 x 25
 constexpr int ZS = 8;              // row stride of the Z panel (16-byte aligned rows)
-constexpr int OFF_S = 600;         // scratch: U 6x24 (predict) | Z 24x8 (update)
-constexpr int OFF_J = 792;         // Jacobian record of the current predict (85 words, predict) |
-constexpr int OFF_E = 792;         //   24 error-state words (update; the record is dead by then)
-constexpr int REGION_MIN = 880;
+constexpr int OFF_S = 600;         // scratch: U 6x24 [600,744) in predict | Z 24x8 [600,792) in update
+constexpr int OFF_J = 744;         // Jacobian record of the current predict (85 words, predict only:
+                                   //   the update's Z panel grows over it once it is dead)
+constexpr int OFF_E = 792;         // 24 error-state words (update)
+constexpr int REGION_MIN = 832;
 // regions of the instances sharing a wave are staggered so that their windows fall on
 // different banks: REGION = LPI (mod 32) (conflict-free for the 8-byte accesses below)
 __host__ __device__ constexpr int region_words(int lpi) {
