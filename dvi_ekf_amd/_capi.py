@@ -44,6 +44,7 @@ SIGNATURES = {
     "dvi_eskf_step": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_epoch": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_get_calibration": (_i, [_vp, _vp, _vp]),
+    "dvi_eskf_flush": (_i, [_vp, _vp]),
     "dvi_eskf_raw_P": (_vp, [_vp]),
     "dvi_eskf_raw_x": (_vp, [_vp]),
     "dvi_eskf_set_lanes_per_instance": (_i, [_vp, _i]),

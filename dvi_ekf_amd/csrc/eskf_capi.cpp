@@ -23,6 +23,7 @@ struct dvi_eskf {
     void* d_res;        // [B][8]
     void* d_e;          // [B][24]
     int32_t* d_status;  // [B]
+    bool pending;       // d_e / d_status hold an update whose injection into d_x is still due
 };
 
 namespace {
@@ -85,6 +86,25 @@ struct DeviceGuard {
     }
 };
 
+eskf::StepArgs base_args(const dvi_eskf* h) {
+    eskf::StepArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.P = h->d_P; a.xs = h->d_x;
+    a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status;
+    a.B = h->B;
+    a.rounds = 1;
+    return a;
+}
+
+// apply a deferred injection so that d_x is the state the caller expects to see
+int flush_pending(dvi_eskf* h, hipStream_t stream) {
+    if (!h->pending) return DVI_ESKF_OK;
+    eskf::StepArgs a = base_args(h);
+    if (eskf::launch_flush(h->dtype, a, h->hp, stream) != hipSuccess) return DVI_ESKF_EHIP;
+    h->pending = false;
+    return DVI_ESKF_OK;
+}
+
 int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_pi, const void* om, const void* acc,
                 int imu_pi, const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out,
                 int32_t* status, void* stream) {
@@ -96,22 +116,21 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
     if (!ensure_jcap(h, n_pred)) return DVI_ESKF_ENOMEM;
-    eskf::StepArgs a;
-    a.P = h->d_P; a.xs = h->d_x;
-    a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status;
+    eskf::StepArgs a = base_args(h);
     a.dt = dt; a.om = om; a.acc = acc;
     a.pos = pos; a.quat = quat; a.notch = notch;
     a.K_out = do_update ? K_out : nullptr;
     a.status = do_update ? status : nullptr;
-    a.B = h->B;
     a.n_pred = n_pred;
     a.do_update = do_update ? 1 : 0;
     a.dt_stride = dt_pi ? 1 : 0;
     a.imu_stride = imu_pi ? 1 : 0;
     a.meas_stride = meas_pi ? 1 : 0;
-    a.rounds = 1;
+    a.apply_pending = h->pending ? 1 : 0;
     hipError_t e = eskf::launch_step(h->dtype, h->lpi, a, h->hp, (hipStream_t)stream);
-    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+    if (e != hipSuccess) return DVI_ESKF_EHIP;
+    h->pending = do_update != 0;      // this update's injection is applied by the next step or a flush
+    return DVI_ESKF_OK;
 }
 
 }  // namespace
@@ -128,7 +147,7 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     if (!g.ok) return DVI_ESKF_ENODEV;
     dvi_eskf* h = new (std::nothrow) dvi_eskf();
     if (!h) return DVI_ESKF_ENOMEM;
-    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 32;
+    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 32; h->pending = false;
     h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
     h->hp.frozen_mask = 0;
     for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);
@@ -152,6 +171,7 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     *out = nullptr;
     DeviceGuard g(src->device);
     if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(const_cast<dvi_eskf*>(src), (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
     dvi_eskf* h = new (std::nothrow) dvi_eskf(*src);
     if (!h) return DVI_ESKF_ENOMEM;
     const size_t es = elem_size(src->dtype);
@@ -174,6 +194,8 @@ int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
     if (!dst || !src || dst->B != src->B || dst->dtype != src->dtype || dst->device != src->device) return DVI_ESKF_EINVAL;
     DeviceGuard g(src->device);
     if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(const_cast<dvi_eskf*>(src), (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+    dst->pending = false;             // whatever was due on dst is overwritten
     const size_t es = elem_size(src->dtype);
     hipStream_t s = (hipStream_t)stream;
     if (hipMemcpyAsync(dst->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
@@ -216,6 +238,7 @@ int dvi_eskf_set_state(dvi_eskf* h, const void* x26, const void* P576, const voi
     if (!h) return DVI_ESKF_EINVAL;
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(h, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
     hipError_t e = eskf::launch_pack(h->dtype, h->B, x26, P576, om3, acc3, qo4, h->d_x, h->d_P, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
@@ -224,6 +247,7 @@ int dvi_eskf_get_state(const dvi_eskf* h, void* x26, void* P576, void* om3, void
     if (!h) return DVI_ESKF_EINVAL;
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(const_cast<dvi_eskf*>(h), (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
     hipError_t e = eskf::launch_unpack(h->dtype, h->B, h->d_x, h->d_P, x26, P576, om3, acc3, qo4, nullptr,
                                        (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
@@ -233,6 +257,7 @@ int dvi_eskf_get_calibration(const dvi_eskf* h, void* dofs_out, void* stream) {
     if (!h || !dofs_out) return DVI_ESKF_EINVAL;
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(const_cast<dvi_eskf*>(h), (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
     hipError_t e = eskf::launch_unpack(h->dtype, h->B, h->d_x, h->d_P, nullptr, nullptr, nullptr, nullptr, nullptr,
                                        dofs_out, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
@@ -258,6 +283,13 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_pi, const voi
                    const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out, int32_t* status,
                    void* stream) {
     return step_common(h, n_pred, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream);
+}
+
+int dvi_eskf_flush(dvi_eskf* h, void* stream) {
+    if (!h) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    return flush_pending(h, (hipStream_t)stream);
 }
 
 void* dvi_eskf_raw_P(dvi_eskf* h) { return h ? h->d_P : nullptr; }

@@ -69,9 +69,11 @@ struct StepArgs {
     int do_update;
     int dt_stride, imu_stride, meas_stride;
     int rounds;         // instances per wave slot in the covariance kernel (set by the launcher)
+    int apply_pending;  // the workspace holds the error state of the previous update: inject it first
 };
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
+hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
                        const void* qo4, void* xs, void* Ppk, hipStream_t stream);
 hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,

@@ -459,7 +459,15 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
-    __syncthreads();                               // every read of the old state precedes its update
+    const bool inject_now = a.apply_pending && !(a.status_ws[b] & DVI_STATUS_SINGULAR);
+    T epend[24];
+    if (inject_now) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) epend[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i];
+    }
+    __syncthreads();                               // every read of the old state (and of the pending
+                                                   // error state) precedes this step's writes
+    if (inject_now) inject_error(s, epend);        // the previous update's injection (both roles)
     if (jac_role && a.n_pred == 0) return;
     for (int ip = 0; ip < a.n_pred; ++ip) {
         const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
@@ -526,41 +534,41 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
         gr[6] = ang_notch - s.notch[0];
         gr[7] = flag;                                         // asin argument was clamped
     }
-    if (a.n_pred > 0) store_state(xs, a.B, b, s);
+    if (a.n_pred > 0 || a.apply_pending) store_state(xs, a.B, b, s);
 }
 
-// ---- lane-per-instance: error injection (ErrorState.from_array state.py:105-129, State.__add__ 46-60)
+// ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
 template <typename T>
-__global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T> prm) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
-    const int st = a.status_ws[b];
-    if (a.status) a.status[b] = st;
-    if (st & DVI_STATUS_SINGULAR) return;                     // Filter.py:356-361: nothing changes
-    T* xs = reinterpret_cast<T*>(a.xs);
-    const T* e = reinterpret_cast<const T*>(a.e) + b * 24;
-    T q[4], qc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { q[i] = xs[(6 + i) * a.B + b]; qc[i] = xs[(22 + i) * a.B + b]; }
+__device__ __forceinline__ void inject_error(State<T>& s, const T* e) {
     T th[3] = {e[6], e[7], e[8]}, thc[3] = {e[21], e[22], e[23]};
     T dq[4], dqc[4], qn[4], qcn[4];
     quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
     quat_about_axis(t_sqrt(thc[0] * thc[0] + thc[1] * thc[1] + thc[2] * thc[2]), th, dqc);   // sic (state.py:124)
-    quat_mul(q, dq, qn);
+    quat_mul(s.q, dq, qn);
     quat_nrm(qn);
-    quat_mul(qc, dqc, qcn);
+    quat_mul(s.qc, dqc, qcn);
     quat_nrm(qcn);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        xs[(0 + i) * a.B + b] += e[i];
-        xs[(3 + i) * a.B + b] += e[3 + i];
-        xs[(16 + i) * a.B + b] += e[15 + i];
-        xs[(19 + i) * a.B + b] += e[18 + i];
-    }
+    for (int i = 0; i < 3; ++i) { s.p[i] += e[i]; s.v[i] += e[3 + i]; s.notch[i] += e[15 + i]; s.pc[i] += e[18 + i]; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) xs[(10 + i) * a.B + b] += e[9 + i];
+    for (int i = 0; i < 6; ++i) s.dofs[i] += e[9 + i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xs[(6 + i) * a.B + b] = qn[i]; xs[(22 + i) * a.B + b] = qcn[i]; }
+    for (int i = 0; i < 4; ++i) { s.q[i] = qn[i]; s.qc[i] = qcn[i]; }
+}
+
+// ---- lane-per-instance: apply a pending injection to the stored state.  A step leaves the error
+// state of its update in the workspace; the next step's pre kernel injects it on the fly, and this
+// kernel is only launched when the state is read or replaced in between (dvi_eskf_flush).
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T> prm) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    if (a.status_ws[b] & DVI_STATUS_SINGULAR) return;         // Filter.py:356-361: nothing changes
+    T* xs = reinterpret_cast<T*>(a.xs);
+    State<T> s;
+    load_state(xs, a.B, b, s);
+    inject_error(s, reinterpret_cast<const T*>(a.e) + b * 24);
+    store_state(xs, a.B, b, s);
 }
 
 // ----------------------------------------------------------------------------------
@@ -948,7 +956,10 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
             }
         }
         group_sync();
-        if (lig == 0 && valid) a.status_ws[inst] = status;
+        if (lig == 0 && valid) {
+            a.status_ws[inst] = status;
+            if (a.status) a.status[inst] = status;
+        }
     }
 
     // ---- store: lower triangle -> packed record (16-byte stores) --------------------------
@@ -1048,7 +1059,6 @@ static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipSt
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
-    const unsigned sblocks = (unsigned)((a.B + 255) / 256);
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
     hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), 0, stream, a, prm);
     hipError_t e = hipGetLastError();
@@ -1064,12 +1074,20 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
-    // 3. lane-per-instance: error injection
-    if (a.do_update) {
-        hipLaunchKernelGGL(eskf_post_kernel<T>, dim3(sblocks), dim3(256), 0, stream, a, prm);
-        e = hipGetLastError();
-    }
+    // 3. the error injection is deferred: the next pre kernel (or dvi_eskf_flush) applies it
     return e;
+}
+
+template <typename T>
+static hipError_t launch_flush_typed(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+    if (a.B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(eskf_post_kernel<T>, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a, prm);
+    return hipGetLastError();
+}
+
+hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
+    if (dtype == 0) return launch_flush_typed<double>(a, make_dev_params<double>(hp), stream);
+    return launch_flush_typed<float>(a, make_dev_params<float>(hp), stream);
 }
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream) {

@@ -123,6 +123,12 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_per_instance,
  * buffer) is done by the caller -- see dvi_ekf_amd/dist.py. */
 int dvi_eskf_get_calibration(const dvi_eskf* h, void* dofs_out, void* stream);
 
+/* The error injection of an update (state.py:46-60) is deferred: it is applied by the next
+ * predict/update/step/epoch call, or by any call that reads or replaces the state (get_state,
+ * set_state, get_calibration, clone, copy_state).  dvi_eskf_flush applies it explicitly -- needed
+ * only before looking at dvi_eskf_raw_x(). */
+int dvi_eskf_flush(dvi_eskf* h, void* stream);
+
 /* Raw device buffers (zero-copy views for profiling / checkpointing): packed lower
  * triangle of P [B,300] and the persistent state block, structure-of-arrays [36,B] with
  * words x26 | om_old3 | acc_old3 | q_old4. */
