@@ -29,7 +29,9 @@ if trace:
         info["launches"] = len(d)
         info["avg_ns"] = sum(d) / len(d)
         res["step_kernels"][key] = info
-    res["step_avg_ns_sum_of_kernels"] = sum(v["avg_ns"] for v in res["step_kernels"].values())
+    # per step: kernels that do not run every step (the flush) are weighted by their launch count
+    ref = max(v["launches"] for v in res["step_kernels"].values())
+    res["step_avg_ns_sum_of_kernels"] = sum(v["avg_ns"] * v["launches"] / ref for v in res["step_kernels"].values())
 if len(sys.argv) >= 5:
     pm = {}
     calib = {}
@@ -51,8 +53,11 @@ if len(sys.argv) >= 5:
         # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced
         # streaming read (calibrated in the same run on the runtime's copyBuffer of known size);
         # WRITE_SIZE is exact.  Units are KiB.
-        rd = sum(v["mean_KiB"] for v in pm["FETCH_SIZE"].values()) * 1024 * 2
-        wr = sum(v["mean_KiB"] for v in pm["WRITE_SIZE"].values()) * 1024
+        def per_step(d):
+            ref = max(v["launches"] for v in d.values())
+            return sum(v["mean_KiB"] * v["launches"] / ref for v in d.values())
+        rd = per_step(pm["FETCH_SIZE"]) * 1024 * 2
+        wr = per_step(pm["WRITE_SIZE"]) * 1024
         res["hbm_bytes_per_launch"] = rd + wr   # per step: all kernels of one predict+update pair
         res["hbm_read_bytes_per_launch_corrected_x2"] = rd
         res["hbm_write_bytes_per_launch"] = wr
