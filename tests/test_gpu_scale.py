@@ -130,3 +130,19 @@ def test_config5_long_horizon_epochs_fp64_and_fp32():
     assert bool((x64 == x64[0:1]).all())
     assert np.abs(x64[sample].cpu().numpy() - o.x).max() <= 1e-9
     assert bool(torch.isfinite(f32.x).all()) and bool(torch.isfinite(f32.P).all())
+
+
+def test_config4_monte_carlo_driver_single_gpu():
+    """config #4 on one GPU (the multi-GPU run only adds the all-gather, covered by
+    tests/test_dist_gloo.py): noise streams are reproducible from the seed, instance 0 is the
+    noise-free reference run, and the DOF-MSE statistic is finite."""
+    from dvi_ekf_amd.montecarlo import run_monte_carlo
+    a = run_monte_carlo(4096, frames=6, seed=4)
+    b = run_monte_carlo(4096, frames=6, seed=4)
+    assert a == b
+    assert a["instances_ok"] + a["instances_flagged"] <= 4096 and a["instances_ok"] > 3000
+    assert np.isfinite(a["dof_mse_mean"]) and a["dof_mse_mean"] > 0
+    # instance 0 = the reference's own (noise-free, unperturbed) run: DOFs move only by rounding-level K.res
+    assert np.allclose(a["reference_instance_dofs"][3:], [0, 0, 20], atol=1e-3)
+    c = run_monte_carlo(4096, frames=6, seed=5)
+    assert c["dof_mse_mean"] != a["dof_mse_mean"]
