@@ -142,7 +142,13 @@ def test_config4_monte_carlo_driver_single_gpu():
     assert a == b
     assert a["instances_ok"] + a["instances_flagged"] <= 4096 and a["instances_ok"] > 3000
     assert np.isfinite(a["dof_mse_mean"]) and a["dof_mse_mean"] > 0
-    # instance 0 = the reference's own (noise-free, unperturbed) run: DOFs move only by rounding-level K.res
-    assert np.allclose(a["reference_instance_dofs"][3:], [0, 0, 20], atol=1e-3)
+    # instance 0 = the noise-free, unperturbed run with unfrozen DOFs: must equal the oracle's estimate
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=False, frozen=(0,) * 6, interframe=1)
+    prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, True, sa, so, Q, R)
+    o = c_oracle.OracleBatch(prm, ri.x0[None, :], ri.P0, ri.om0, ri.acc0)
+    for k in range(6):
+        o.predict(ri.dt[k], ri.om[k], ri.acc[k])
+        o.update(ri.pos[k], ri.quat[k], ri.notch[k])
+    assert np.abs(np.array(a["reference_instance_dofs"]) - o.x[0, 10:16]).max() <= 1e-9
     c = run_monte_carlo(4096, frames=6, seed=5)
     assert c["dof_mse_mean"] != a["dof_mse_mean"]
