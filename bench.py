@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per instance (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--mode", default="pair", choices=["pair", "predict", "update"],
                     help="diagnostic: time only the predict or only the update launch (not the metric)")
     args = ap.parse_args()
@@ -85,13 +86,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if os.environ.get("DVI_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("DVI_BENCH_BACKEND", "nccl") == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from dvi_ekf_amd.workloads import monte_carlo_pairs
     B, H, K, W = args.batch, args.horizon, args.steps, args.warmup
@@ -110,21 +116,77 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+            if os.environ.get("DVI_BENCH_BACKEND", "nccl") == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
+
+    backend = os.environ.get("DVI_BENCH_BACKEND", "nccl")   # "gloo" only for rehearsing the N>1 path on one GPU
+
+    def all_gather_dofs(dofs):
+        if backend == "nccl":
+            dist.all_gather(gathered, dofs)                  # RCCL: the only collective on the path
+        else:
+            host = [torch.empty((B, 6), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(host, dofs.cpu())
+            for g_, h_ in zip(gathered, host):
+                g_.copy_(h_)
 
     for k in range(W):
         step(k)
     gathered = None
     if dist is not None:   # warm the collective up as well
         gathered = [torch.empty((B, 6), dtype=torch.float64, device=dev) for _ in range(world)]
-        dist.all_gather(gathered, f.calibration())
+        all_gather_dofs(f.calibration())
     torch.cuda.synchronize(dev)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    # One horizon (state restore + H pair-steps) is captured into a HIP graph: at ~0.19 ms of
+    # kernel time per step the Python/ctypes launch path would otherwise show up in the step time.
+    graph = None
+    if args.mode == "pair" and not args.no_graph and K >= H:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for k in range(H):
+                step(k)                                      # warm-up on the capture stream
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for k in range(H):
+                step(k)
+        torch.cuda.synchronize(dev)
+
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for k in range(K):
+    k = 0
+    if graph is not None:
+        while k + H <= K:
+            graph.replay()
+            k += H
+    while k < K:                                             # remainder (or everything, without a graph)
+        i = k % H
+        if i == 0:
+            f.copy_state_from(snap)
+        if args.mode == "pair":
+            f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+        elif args.mode == "predict":
+            f.predict(wl.dt[i], wl.om[i], wl.acc[i])
+        else:
+            f.update(wl.pos[i], wl.quat[i], wl.notch[i])
+        k += 1
+    dofs = f.calibration()
+    if dist is not None:
+        all_gather_dofs(dofs)
+    torch.cuda.synchronize(dev)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # kernel time of one step: HIP events around each launch group, eager, outside the timed region
+    n_ev = min(K, 2 * H)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+    for k in range(n_ev):
         i = k % H
         if i == 0:
             f.copy_state_from(snap)
@@ -136,12 +198,7 @@ def main():
         else:
             f.update(wl.pos[i], wl.quat[i], wl.notch[i])
         ev[k][1].record()
-    dofs = f.calibration()
-    if dist is not None:
-        dist.all_gather(gathered, dofs)     # RCCL: the only collective on the path
     torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
 
     # every instance must have done the full work: no singular / skipped updates, finite state
     st = status.cpu().numpy()
@@ -149,7 +206,7 @@ def main():
     ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
@@ -184,6 +241,7 @@ def main():
                             "pairs (dt=1.0), unfrozen DOFs, per-instance IMU/camera noise and perturbed ICs",
                 "batch_per_gpu": B, "global_batch": B * world, "horizon_between_state_restores": H,
                 "state_restore_in_timed_region": True, "lanes_per_instance": args.lanes or 32,
+                "hip_graph": graph is not None,
                 "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
             },
             "roofline": {
