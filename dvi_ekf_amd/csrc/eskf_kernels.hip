@@ -6,21 +6,18 @@
 // probe forward kinematics (models/Probe.py:147-167,431-480), in closed form
 // (SURVEY.md App. A/B).
 //
-// Execution model: a 64-thread block is ONE wavefront.  The wavefront hosts
-// G = 64 / LPI filter instances, LPI lanes each (LPI = 12 -> 5 instances per wave;
-// LPI = 64 -> the one-wavefront-per-instance layout).  Each instance owns a private LDS
-// region holding its 24x24 covariance (row stride 25 so that row- and column-owner
-// accesses are both bank-conflict free), a 6x24 / 24x7 scratch panel and its state.
-// The instance's "scalar" work (nominal propagation, Jacobian blocks, residual,
-// injection) is evaluated redundantly by its LPI lanes and stays in registers; the
-// matrix work is split over the lanes by ownership of columns / rows so that each
-// phase needs no intra-phase synchronisation.
+// One predict(+update) step = eskf_pre_kernel (lane per instance: nominal state, Jacobian blocks,
+// residual) -> eskf_cov_kernel (LPI lanes per instance: covariance propagation, gain, covariance
+// update) ; the error injection of an update is applied by the next step's pre kernel or, when the
+// state is read in between, by eskf_post_kernel.  See the "Work split" comment below and
+// DESIGN.md section 4.
 //
-// HBM layout (batch-major, one contiguous record per instance -- a wave reads whole
-// records, i.e. contiguous 2.4 KB / 288 B segments):
-//   P  [B][300]  symmetric-packed: 12 "double rows" r of 25 words, word c of double row
-//                r is P[r][c] for c <= r, else P[23-r][c-r-1]
-//   xs [B][36]   x26 | om_old3 | acc_old3 | q_old4   (R_WB_old = Rm(q_old), Filter.py:227)
+// HBM layout:
+//   P  [B][300]  symmetric-packed, one contiguous 2.4 KB record per instance: 12 "double rows" r
+//                of 25 words, word c of double row r is P[r][c] for c <= r, else P[23-r][c-r-1]
+//   xs [36][B]   structure-of-arrays state: words x26 | om_old3 | acc_old3 | q_old4
+//                (R_WB_old = Rm(q_old), Filter.py:227)
+//   J  [n][B][88], res [B][8], e [B][24], status [B]   workspace between the kernels
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -375,7 +372,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
 }
 
 // ----------------------------------------------------------------------------------
-// Work split (round-1 v2).  The per-instance "scalar" arithmetic -- probe trigonometry,
+// Work split.  The per-instance "scalar" arithmetic -- probe trigonometry,
 // nominal propagation, Jacobian blocks, residual, injection -- does not depend on the
 // covariance, and CDNA4 has no scalar fp64 ALU: evaluated inside a wave that is shared by a
 // few instances it costs a full wave issue per instruction.  It therefore runs in two small
