@@ -183,9 +183,9 @@ struct Jac {
     T A[9];     // Fx[3:6,6:9]  = -dt R_o [a_o]x            (Filter.py:254)
     T Th[9];    // Fx[6:9,6:9]  = Rm(Om_old)^T              (Filter.py:255,132-134)
     T Bm[9], Cm[18], Dm[12], Em[9];
-    T N6[18];   // Fi[18:24,3:6] (6x3): dt R_o [p]x ; -dt R_BC^T
     T dt;
-};
+    T N6[18];   // Fi[18:24,3:6] (6x3): dt R_o [p]x ; -dt R_BC^T
+};              // member order == word order of the Jacobian record in HBM (J_A .. J_N6 below)
 
 // Filter._predict_nominal (Filter.py:232-247) + eqns.f_predict (equations.py:44-50,72-100)
 // + State.from_array (state.py:62-74), then the Jacobian blocks of Filter._predict_error /
@@ -393,21 +393,6 @@ constexpr int JW = 88;          // words per Jacobian record: A9 Th9 Bm9 Cm18 Dm
 constexpr int J_A = 0, J_TH = 9, J_BM = 18, J_CM = 27, J_DM = 45, J_EM = 57, J_DT = 66, J_N6 = 67;
 constexpr int J_CORE = 67, J_FULL = 85;
 
-template <typename T>
-__device__ __forceinline__ void store_jac(const Jac<T>& J, T* g, bool with_n6) {
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { g[J_A + i] = J.A[i]; g[J_TH + i] = J.Th[i]; g[J_BM + i] = J.Bm[i]; g[J_EM + i] = J.Em[i]; }
-#pragma unroll
-    for (int i = 0; i < 18; ++i) g[J_CM + i] = J.Cm[i];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) g[J_DM + i] = J.Dm[i];
-    g[J_DT] = J.dt;
-    if (with_n6) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) g[J_N6 + i] = J.N6[i];
-    }
-}
-
 // state record, structure-of-arrays: word w of instance b at xs[w * B + b]
 // words: x26 | om_old3 | acc_old3 | q_old4
 template <typename T>
@@ -445,7 +430,8 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
     // overwrites it (block barrier).  Wave 1 stages its 67-word records in LDS (row stride 69:
     // conflict-free) and writes them out as whole records with 16-byte stores -- a lane-per-instance
     // store of an array-of-structures would touch 64 different cache lines per instruction.
-    constexpr int JS = 69;
+    constexpr int JS = 85;                             // = sizeof(Jac<T>) / sizeof(T): odd -> conflict-free
+    static_assert(sizeof(Jac<T>) == JS * sizeof(T), "Jac<T> must be the 85-word record");
     __shared__ __attribute__((aligned(16))) T sJ[64 * JS];
     const int lane = threadIdx.x & 63;
     const bool jac_role = threadIdx.x >= 64;           // wave-uniform
@@ -466,6 +452,7 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
                                                    // error state) precedes this step's writes
     if (inject_now) inject_error(s, epend);        // the previous update's injection (both roles)
     if (jac_role && a.n_pred == 0) return;
+    const int npiece = prm.q_gyro ? 43 : 34;       // 16-byte pieces of a record: 85 / 67 words
     for (int ip = 0; ip < a.n_pred; ++ip) {
         const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
         const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
@@ -473,34 +460,30 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
         const T* gac = reinterpret_cast<const T*>(a.acc) + so;
         const T dt = gdt[0];
         T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
-        Jac<T> J;
         if (jac_role) {
+            // the blocks are written straight into this lane's staging row (the struct IS the record),
+            // so they do not occupy registers; only this wavefront touches sJ: wave-level ordering
+            Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
             predict_scalar<T, false, true>(s, prm, dt, om_n, acc_n, J);
-            if (prm.q_gyro) {       // 85-word records do not fit the staging rows: direct stores
-                if (live) store_jac(J, reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b) * JW, true);
-            } else {
-                // only this wavefront touches sJ: wave-level ordering is enough
-                store_jac(J, sJ + lane * JS, false);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
-                const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
-                // record r: words [0, 67) -> 34 pieces of 2 words (the last piece carries one pad word)
-                for (int r = 0; r < nrec; ++r) {
-                    if (lane < 34) {
-                        using T2 = typename Vec2<T>::type;
-                        T2 v;
-                        v.x = sJ[r * JS + 2 * lane];
-                        v.y = sJ[r * JS + 2 * lane + 1];
-                        reinterpret_cast<T2*>(gJ + (int64_t)r * JW)[lane] = v;
-                    }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
+            const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
+            for (int r = 0; r < nrec; ++r) {
+                if (lane < npiece) {
+                    using T2 = typename Vec2<T>::type;
+                    T2 v;
+                    v.x = sJ[r * JS + 2 * lane];
+                    v.y = (2 * lane + 1 < JS) ? sJ[r * JS + 2 * lane + 1] : T(0);
+                    reinterpret_cast<T2*>(gJ + (int64_t)r * JW)[lane] = v;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
+            Jac<T> J;
             predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
         }
     }
