@@ -580,7 +580,7 @@ __device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
 }
 
 template <typename T, int LPI>
-__global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> prm) {
+__global__ __launch_bounds__(64, 2) void eskf_cov_kernel(StepArgs a, DevParams<T> prm) {
     constexpr int G = 64 / LPI;
     constexpr int REGION = region_words(LPI);
     __shared__ T smem[G * REGION];
@@ -965,6 +965,429 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
 }
 
 // ----------------------------------------------------------------------------------
+// row-resident covariance kernel (selector DVI_ESKF_LANES_ROWS): lane i of an instance keeps row i
+// of P (= column i, P is symmetric) in registers for the whole step; 32 lanes per instance (24
+// active), two instances per wave.  LDS is used for exchanges only:
+//   load     packed record -> lower-triangle image, each lane gathers its row
+//   predict  P' = Fx P Fx^T as two applications of v -> Fx v: lane i computes (Fx P)[:,i] and
+//            writes it as row i of W = P Fx^T; lane j reads column j of W and applies Fx again,
+//            which leaves row j of P' in its registers.  One 24x24 transposition per predict.
+//   update   every lane publishes P[i,sel] (7 words): rows sel of that panel are S; the same panel
+//            then carries Z = P H^T L^-T for the rank-7 downdate P[i,:] -= (Z D^-1)[i,:] Z^T
+//   reset    G P G^T: column part in registers; the six rows it touches are gathered from the
+//            other lanes' column results by symmetry
+// The Jacobian record is read from LDS with group-uniform (broadcast) addresses.
+// ----------------------------------------------------------------------------------
+namespace rowk {
+// exchange image: row stride PS = 25 (conflict-free row writes and column reads)
+constexpr int XS = 10;             // row stride of the 24 x 7 panels: 16-byte aligned rows, 2-way bank conflicts at most
+constexpr int R_BUF = 0;         // 24 x 25 exchange image | [24][XS] panel of the reset
+constexpr int R_X = 600;         // [24][XS]: P[:,sel], then Z
+constexpr int R_E = 840;         // 24 error-state words
+constexpr int R_J = 864;         // Jacobian record, blocks re-laid on even offsets (16-byte reads)
+constexpr int L_A = 0, L_TH = 10, L_BM = 20, L_CM = 30, L_DM = 48, L_EM = 60, L_DT = 70, L_N6 = 72;
+constexpr int R_REGION = 954;        // words per instance (even)
+__device__ __forceinline__ int lds_word(int e) {   // HBM record word -> LDS word
+    return e + (e >= J_TH) + (e >= J_BM) + (e >= J_CM) + (e >= J_DT) + (e >= J_N6);
+}
+
+// o = Fx v  (Fx of Filter.py:270-342 with the structure of SURVEY.md App. A; same blocks as
+// phases 1/2 of eskf_cov_kernel)
+template <typename T>
+__device__ __forceinline__ void fx_apply(const T* sJ, const T (&v)[24], T (&o)[24]) {
+    const T dt = sJ[L_DT];
+    {
+        T A[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) A[k] = sJ[L_A + k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[r] = v[r] + dt * v[3 + r];
+            o[3 + r] = v[3 + r] + A[3 * r] * v[6] + A[3 * r + 1] * v[7] + A[3 * r + 2] * v[8];
+        }
+    }
+    {
+        T Th[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Th[k] = sJ[L_TH + k];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o[6 + r] = Th[3 * r] * v[6] + Th[3 * r + 1] * v[7] + Th[3 * r + 2] * v[8];
+    }
+#pragma unroll
+    for (int k = 9; k < 15; ++k) o[k] = v[k];
+    o[15] = v[15] + dt * v[16];
+    o[16] = v[16] + dt * v[17];
+    o[17] = v[17];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T Bm[3], Cm[6];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Bm[k] = sJ[L_BM + 3 * r + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Cm[k] = sJ[L_CM + 6 * r + k];
+        T u = dt * v[3 + r] + v[16 + r];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) u += Bm[k] * v[6 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) u += Cm[k] * v[9 + k];
+        o[18 + r] = u;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T Dm[4], Em[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Dm[k] = sJ[L_DM + 4 * r + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Em[k] = sJ[L_EM + 3 * r + k];
+        T w = Dm[3] * v[15];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w += Dm[k] * v[9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w += Em[k] * v[19 + k];
+        if (r == 1) w += v[22];
+        if (r == 2) w += v[23];
+        o[21 + r] = w;
+    }
+}
+}  // namespace rowk
+
+template <typename T>
+__global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
+    using namespace rowk;
+    constexpr int LPI = 32, G = 2;
+    __shared__ __attribute__((aligned(16))) T smem[G * R_REGION];
+
+    const int lane = threadIdx.x;
+    const int grp = lane >> 5;
+    const int lig = lane & 31;
+    const bool active = lig < 24;
+    const int row0 = active ? lig : 23;     // idle lanes shadow row 23 and write nothing
+
+    T* sB = smem + grp * R_REGION + R_BUF;
+    T* sX = smem + grp * R_REGION + R_X;
+    T* sE = smem + grp * R_REGION + R_E;
+    T* sJ = smem + grp * R_REGION + R_J;
+
+    const int jwords = prm.q_gyro ? J_FULL : J_CORE;
+    constexpr int NJ = (J_FULL + LPI - 1) / LPI;
+    constexpr int NV = (150 + LPI - 1) / LPI;
+    using T2 = typename Vec2<T>::type;
+
+    const int64_t round_stride = (int64_t)gridDim.x * G;
+    const int64_t slot = (int64_t)blockIdx.x * G + grp;
+    T2 pv[NV];
+    T jv[NJ];
+#define ESKF_ISSUE_LOADS(INST)                                                                     \
+    {                                                                                              \
+        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P) + (INST) * 300); \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
+            const int e2 = lig + k * LPI;                                                          \
+            if (e2 < 150) pv[k] = gP2_[e2];                                                        \
+        }                                                                                          \
+        if (a.n_pred > 0) {                                                                        \
+            const T* gJ_ = reinterpret_cast<const T*>(a.J) + (INST) * JW;                          \
+            _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                       \
+                const int e = lig + k * LPI;                                                       \
+                if (e < jwords) jv[k] = gJ_[e];                                                    \
+            }                                                                                      \
+        }                                                                                          \
+    }
+    {
+        const int64_t i0 = slot < a.B ? slot : a.B - 1;
+        ESKF_ISSUE_LOADS(i0)
+    }
+
+  for (int rnd = 0; rnd < a.rounds; ++rnd) {
+    const int64_t inst_raw = (int64_t)rnd * round_stride + slot;
+    const bool valid = inst_raw < a.B;      // tail: recompute the last instance, write nothing
+    const int64_t inst = valid ? inst_raw : a.B - 1;
+    T* gP = reinterpret_cast<T*>(a.P) + inst * 300;
+    int row = row0;
+    asm volatile("" : "+v"(row));           // per-lane addresses are recomputed per round, not kept in registers
+
+    // ---- packed record -> lower-triangle image; Jacobian record -> LDS ------------------------
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int e2 = lig + k * LPI;
+        if (e2 < 150) {
+            int i, j;
+            unpack_ij(2 * e2, i, j);
+            sB[i * PS + j] = pv[k].x;
+            unpack_ij(2 * e2 + 1, i, j);
+            sB[i * PS + j] = pv[k].y;
+        }
+    }
+    if (a.n_pred > 0) {
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) {
+            const int e = lig + k * LPI;
+            if (e < jwords) sJ[lds_word(e)] = jv[k];
+        }
+    }
+    group_sync();
+    T p[24];                                // row `row` of P
+#pragma unroll
+    for (int j = 0; j < 24; ++j) p[j] = sB[(j <= row) ? row * PS + j : j * PS + row];
+    group_sync();
+
+    // ================================ predict(s) =======================================
+#ifndef ROWS_NO_PREDICT
+    for (int ip = 0; ip < a.n_pred; ++ip) {
+        if (ip > 0) {
+            const T* gJ = reinterpret_cast<const T*>(a.J) + ((int64_t)ip * a.B + inst) * JW;
+            T jn[NJ];
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) {
+                const int e = lig + k * LPI;
+                if (e < jwords) jn[k] = gJ[e];
+            }
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) {
+                const int e = lig + k * LPI;
+                if (e < jwords) sJ[lds_word(e)] = jn[k];
+            }
+            group_sync();
+        }
+        {
+            T o[24];
+            fx_apply(sJ, p, o);             // column `row` of Fx P = row `row` of W = P Fx^T
+            if (active) {
+#pragma unroll
+                for (int l = 0; l < 24; ++l) sB[row * PS + l] = o[l];
+            }
+        }
+        group_sync();
+        {
+            T c[24];
+#pragma unroll
+            for (int k = 0; k < 24; ++k) c[k] = sB[k * PS + row];
+            fx_apply(sJ, c, p);             // column `row` of Fx P Fx^T = row `row` of P'
+        }
+        // Fi Q Fi^T: diagonal entries 3..14 <- Q[i-3], 17 <- Q[12]  (Filter.py:263-264,349)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? prm.qd[k] : T(0);
+        p[17] += (row == 17) ? prm.qd[12] : T(0);
+        if (prm.q_gyro) {   // gyro noise reaches the camera rows through N6 and theta through Fi[6:9,3:6] = I
+            const T* N6 = sJ + L_N6;
+            if (row >= 18) {
+                const int ar = row - 18;
+                T na[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    na[k] = N6[3 * ar + k] * prm.qd[3 + k];
+                    p[6 + k] += na[k];
+                }
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[18 + b] += na[k] * N6[3 * b + k];
+            } else if (row >= 6 && row < 9) {
+                const int k = row - 6;
+                const T qk = (k == 0) ? prm.qd[3] : (k == 1) ? prm.qd[4] : prm.qd[5];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) p[18 + b] += N6[3 * b + k] * qk;
+            }
+        }
+        group_sync();
+    }
+
+#endif
+    // ================================ update ===========================================
+#ifndef ROWS_NO_UPDATE
+    constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
+    T z[7], rd[7];
+    bool ok = false;
+    int status = 0;
+    if (a.do_update) {
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < 7; ++m) sX[row * XS + m] = p[sel[m]];
+        }
+        group_sync();
+        // ---- S = H P H^T + R = rows sel of the panel; LDL^T, redundantly in every lane ---------
+        T Lm[21], d[7];          // unit-lower L packed by rows: L[i][j] at i(i-1)/2 + j
+        ok = true;
+        {
+            T S[28];
+#pragma unroll
+            for (int i = 0; i < 7; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) S[i * (i + 1) / 2 + j] = sX[sel[i] * XS + j] + (i == j ? prm.r[i] : T(0));
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                T dj = S[j * (j + 1) / 2 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) dj -= Lm[j * (j - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
+                d[j] = dj;
+                ok = ok && (dj != T(0)) && t_finite(dj);
+                rd[j] = T(1) / dj;
+#pragma unroll
+                for (int i = j + 1; i < 7; ++i) {
+                    T v = S[i * (i + 1) / 2 + j];
+#pragma unroll
+                    for (int k = 0; k < j; ++k) v -= Lm[i * (i - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
+                    Lm[i * (i - 1) / 2 + j] = v * rd[j];
+                }
+            }
+        }
+        const T* gres = reinterpret_cast<const T*>(a.res) + inst * 8;
+        T res[7];
+#pragma unroll
+        for (int m = 0; m < 7; ++m) res[m] = gres[m];
+        status = ok ? 0 : DVI_STATUS_SINGULAR;
+        if (gres[7] != T(0)) status |= DVI_STATUS_NONFINITE;
+
+        // ---- Z[i,:] L^T = P[i,sel]; K[i,:] = (Z D^-1) L^-1; e_i = K[i,:] res -------------------
+        if (ok) {
+            T k[7];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                T v = p[sel[m]];
+#pragma unroll
+                for (int n = 0; n < m; ++n) v -= z[n] * Lm[m * (m - 1) / 2 + n];
+                z[m] = v;
+            }
+#pragma unroll
+            for (int m = 6; m >= 0; --m) {
+                T v = z[m] * rd[m];
+#pragma unroll
+                for (int n = m + 1; n < 7; ++n) v -= k[n] * Lm[n * (n - 1) / 2 + m];
+                k[m] = v;
+            }
+            T e = T(0);
+#pragma unroll
+            for (int m = 0; m < 7; ++m) e += k[m] * res[m];
+            if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
+            if (active) {
+#pragma unroll
+                for (int m = 0; m < 7; ++m) sX[row * XS + m] = z[m];
+                sE[row] = e;
+                if (valid) {
+                    reinterpret_cast<T*>(a.e)[inst * 24 + row] = e;
+                    if (a.K_out) {
+                        T* gK = reinterpret_cast<T*>(a.K_out) + (inst * 24 + row) * 7;
+#pragma unroll
+                        for (int m = 0; m < 7; ++m) gK[m] = k[m];
+                    }
+                }
+            }
+        }
+    }
+    // the next round's record is fetched while the rank-7 update, the reset and the store run
+    // (issued here, not earlier: the factorisation above needs the registers)
+    if (rnd + 1 < a.rounds) {
+        const int64_t nraw = (int64_t)(rnd + 1) * round_stride + slot;
+        const int64_t ni = nraw < a.B ? nraw : a.B - 1;
+        ESKF_ISSUE_LOADS(ni)
+    }
+    if (a.do_update) {
+        group_sync();
+        T* sY = sB;     // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
+        if (ok) {
+#if !defined(ROWS_CUT) || ROWS_CUT > 3
+            // ---- P[i,:] -= (Z D^-1)[i,:] Z^T (Joseph form with the optimal gain, Filter.py:383-384)
+            T zd[7];
+#pragma unroll
+            for (int m = 0; m < 7; ++m) zd[m] = z[m] * rd[m];
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+                T zj[7];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) zj[m] = sX[j * XS + m];
+                T v = p[j];
+#pragma unroll
+                for (int m = 0; m < 7; ++m) v -= zj[m] * zd[m];
+                p[j] = v;
+                // finish four columns before the panel reads of the next four are issued (otherwise
+                // the scheduler front-loads all 168 panel words and spills)
+                if ((j & 3) == 3) asm volatile("" : "+v"(p[j - 3]), "+v"(p[j - 2]), "+v"(p[j - 1]), "+v"(p[j]) : : "memory");
+            }
+#endif
+            // ---- reset G P G^T (Filter.py:387-390), G = I - [theta/2]x on 6:9 and 21:24.
+            // column part, in registers
+            const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
+            const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
+            {
+                const T a0 = p[6], a1 = p[7], a2 = p[8];
+                p[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
+                p[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
+                p[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
+                const T b0 = p[21], b1 = p[22], b2 = p[23];
+                p[21] = b0 + Gc[2] * b1 - Gc[1] * b2;
+                p[22] = b1 - Gc[2] * b0 + Gc[0] * b2;
+                p[23] = b2 + Gc[1] * b0 - Gc[0] * b1;
+            }
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    sY[row * XS + k] = p[6 + k];
+                    sY[row * XS + 4 + k] = p[21 + k];
+                }
+            }
+            group_sync();
+#if !defined(ROWS_CUT) || ROWS_CUT > 4
+            // row part: only rows 6:9 and 21:24 change.  For a column j outside those blocks
+            // P_new[i][j] = P_new[j][i], which lane j already holds (its column result); inside
+            // them the 3x3 row combination of the column results of the lane's own triple.
+            const bool lo = row >= 6 && row < 9, hi = row >= 21;
+            if (lo || hi) {
+                const int tb = lo ? 6 : 21;
+                const int t = row - tb;
+                const int sw = lo ? t : 4 + t;
+                const T g0 = lo ? Gt[0] : Gc[0], g1 = lo ? Gt[1] : Gc[1], g2 = lo ? Gt[2] : Gc[2];
+                const T k0 = (t == 0) ? T(1) : (t == 1) ? -g2 : g1;
+                const T k1 = (t == 0) ? g2 : (t == 1) ? T(1) : -g0;
+                const T k2 = (t == 0) ? -g1 : (t == 1) ? g0 : T(1);
+                const T* y0 = sY + tb * XS;
+#pragma unroll
+                for (int j = 0; j < 24; ++j) {
+                    const bool jl = j >= 6 && j < 9, jh = j >= 21;
+                    if (jl || jh) {
+                        const int sj = jl ? j - 6 : 4 + j - 21;
+                        p[j] = k0 * y0[sj] + k1 * y0[XS + sj] + k2 * y0[2 * XS + sj];
+                    } else {
+                        p[j] = sY[j * XS + sw];
+                    }
+                }
+            }
+#endif
+        }
+        group_sync();
+        if (lig == 0 && valid) {
+            a.status_ws[inst] = status;
+            if (a.status) a.status[inst] = status;
+        }
+    }
+
+#endif
+    // ---- store: rows -> lower-triangle image -> packed record (16-byte stores) ----------------
+    if (active) {   // (the whole row: the words above the diagonal are never read)
+#pragma unroll
+        for (int j = 0; j < 24; ++j) sB[row * PS + j] = p[j];
+    }
+    group_sync();
+    if (valid) {
+        T2* gP2 = reinterpret_cast<T2*>(gP);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e2 = lig + k * LPI;
+            if (e2 < 150) {
+                int i, j;
+                T2 v;
+                unpack_ij(2 * e2, i, j);
+                v.x = sB[i * PS + j];
+                unpack_ij(2 * e2 + 1, i, j);
+                v.y = sB[i * PS + j];
+                gP2[e2] = v;
+            }
+        }
+    }
+    group_sync();   // the next round overwrites the image
+  }
+#undef ESKF_ISSUE_LOADS
+}
+
+// ----------------------------------------------------------------------------------
 // state import / export between the user-facing layout and the device records
 // ----------------------------------------------------------------------------------
 template <typename T>
@@ -1037,6 +1460,20 @@ static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipSt
 }
 
 template <typename T>
+static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+    constexpr int G = 2;
+    StepArgs b = a;
+    int64_t blocks = (a.B + G - 1) / G;
+    int rounds = 1;
+    while (rounds < 4 && blocks / (rounds * 2) >= 256 * 16) rounds *= 2;
+    b.rounds = rounds;
+    blocks = (a.B + (int64_t)G * rounds - 1) / ((int64_t)G * rounds);
+    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(eskf_cov_rows_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
+    return hipGetLastError();
+}
+
+template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
@@ -1045,6 +1482,7 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (e != hipSuccess) return e;
     // 2. covariance: LPI lanes per instance
     switch (lpi) {
+        case 1:  e = launch_cov_rows<T>(a, prm, stream); break;    // DVI_ESKF_LANES_ROWS
         case 64: e = launch_cov_t<T, 64>(a, prm, stream); break;
         case 32: e = launch_cov_t<T, 32>(a, prm, stream); break;
         case 24: e = launch_cov_t<T, 24>(a, prm, stream); break;
