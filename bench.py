@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536, help="filter instances per GPU")
     ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
-    ap.add_argument("--lanes", type=int, default=0, help="lanes per instance (0 = library default)")
+    ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident; 64/32/24/16/12/8 = LDS-image kernel with that many lanes per instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--mode", default="pair", choices=["pair", "predict", "update"],
@@ -240,14 +240,14 @@ def main():
                 "workload": "BASELINE config #2/#4: Monte-Carlo batch on mandala0_mono, 1:1 predict+update "
                             "pairs (dt=1.0), unfrozen DOFs, per-instance IMU/camera noise and perturbed ICs",
                 "batch_per_gpu": B, "global_batch": B * world, "horizon_between_state_restores": H,
-                "state_restore_in_timed_region": True, "lanes_per_instance": args.lanes or 32,
+                "state_restore_in_timed_region": True, "covariance_kernel": "row-resident" if (args.lanes or 1) == 1 else "lds-image, %d lanes/instance" % args.lanes,
                 "hip_graph": graph is not None,
                 "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "one step = eskf_pre_kernel + eskf_cov_kernel<double,LPI> (dominant) + eskf_post_kernel",
+                "kernel": "one step = eskf_pre_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes) + eskf_post_kernel once per horizon",
                 "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR_F64 * B,
             },

@@ -147,7 +147,7 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     if (!g.ok) return DVI_ESKF_ENODEV;
     dvi_eskf* h = new (std::nothrow) dvi_eskf();
     if (!h) return DVI_ESKF_ENOMEM;
-    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 32; h->pending = false;
+    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 1; h->pending = false;
     h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
     h->hp.frozen_mask = 0;
     for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);

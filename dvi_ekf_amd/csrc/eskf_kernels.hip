@@ -580,7 +580,7 @@ __device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
 }
 
 template <typename T, int LPI>
-__global__ __launch_bounds__(64, 2) void eskf_cov_kernel(StepArgs a, DevParams<T> prm) {
+__global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> prm) {
     constexpr int G = 64 / LPI;
     constexpr int REGION = region_words(LPI);
     __shared__ T smem[G * REGION];
@@ -1131,7 +1131,6 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
     group_sync();
 
     // ================================ predict(s) =======================================
-#ifndef ROWS_NO_PREDICT
     for (int ip = 0; ip < a.n_pred; ++ip) {
         if (ip > 0) {
             const T* gJ = reinterpret_cast<const T*>(a.J) + ((int64_t)ip * a.B + inst) * JW;
@@ -1191,9 +1190,7 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
         group_sync();
     }
 
-#endif
     // ================================ update ===========================================
-#ifndef ROWS_NO_UPDATE
     constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
     T z[7], rd[7];
     bool ok = false;
@@ -1284,7 +1281,6 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
         group_sync();
         T* sY = sB;     // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
         if (ok) {
-#if !defined(ROWS_CUT) || ROWS_CUT > 3
             // ---- P[i,:] -= (Z D^-1)[i,:] Z^T (Joseph form with the optimal gain, Filter.py:383-384)
             T zd[7];
 #pragma unroll
@@ -1302,7 +1298,6 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                 // the scheduler front-loads all 168 panel words and spills)
                 if ((j & 3) == 3) asm volatile("" : "+v"(p[j - 3]), "+v"(p[j - 2]), "+v"(p[j - 1]), "+v"(p[j]) : : "memory");
             }
-#endif
             // ---- reset G P G^T (Filter.py:387-390), G = I - [theta/2]x on 6:9 and 21:24.
             // column part, in registers
             const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
@@ -1325,7 +1320,6 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                 }
             }
             group_sync();
-#if !defined(ROWS_CUT) || ROWS_CUT > 4
             // row part: only rows 6:9 and 21:24 change.  For a column j outside those blocks
             // P_new[i][j] = P_new[j][i], which lane j already holds (its column result); inside
             // them the 3x3 row combination of the column results of the lane's own triple.
@@ -1350,7 +1344,6 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                     }
                 }
             }
-#endif
         }
         group_sync();
         if (lig == 0 && valid) {
@@ -1359,7 +1352,6 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
         }
     }
 
-#endif
     // ---- store: rows -> lower-triangle image -> packed record (16-byte stores) ----------------
     if (active) {   // (the whole row: the words above the diagonal are never read)
 #pragma unroll

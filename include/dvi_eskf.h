@@ -135,8 +135,12 @@ int dvi_eskf_flush(dvi_eskf* h, void* stream);
 void* dvi_eskf_raw_P(dvi_eskf* h);
 void* dvi_eskf_raw_x(dvi_eskf* h);
 
-/* Kernel variant selector for experiments: lanes per filter instance (64 = one
- * wavefront per instance; 32 (default: two instances per wavefront), 24, 16, 12, 8). */
+/* Covariance kernel selector (for experiments and cross-checks).
+ * DVI_ESKF_LANES_ROWS (default): row-resident kernel -- lane i of an instance keeps row i of P in
+ * registers, 32 lanes per instance, two instances per wavefront.
+ * 64 / 32 / 24 / 16 / 12 / 8: LDS-image kernel with that many lanes per instance (64 = one
+ * wavefront per instance).  All variants compute the same step; they differ in rounding only. */
+#define DVI_ESKF_LANES_ROWS 1
 int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes);
 
 const char* dvi_eskf_strerror(int code);

@@ -230,7 +230,7 @@ def test_lane_layout_variants_agree(lpi):
     B = 23   # ragged: not a multiple of any instances-per-wave count
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
     x0 = _perturbed_x0(ri, B)
-    fa = _make(cfg, ri, Q, R, sa, so, B, False, x0)
+    fa = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=32)
     fb = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=lpi)
     ip = 0
     for k in range(2):
@@ -245,11 +245,42 @@ def test_lane_layout_variants_agree(lpi):
         assert torch.equal(a[key], b[key]), key
 
 
-def test_singular_innovation_sets_status_and_leaves_state():
+@pytest.mark.parametrize("tune", [False, True])
+def test_row_resident_kernel_matches_lds_image_kernel(tune):
+    """The two covariance kernels (rows of P in registers / full image in LDS) are the same
+    arithmetic in a different order: they agree to rounding, also with gyro process noise
+    (tune mode, Q[3:6] != 0) and with several predicts per update."""
+    B = 23
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    if tune:
+        Q = Q.copy()
+        Q[3, 3] = Q[4, 4] = Q[5, 5] = 1e-4
+    x0 = _perturbed_x0(ri, B)
+    fa = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=32)
+    fb = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=1)
+    ip = 0
+    for k in range(3):
+        for _ in range(ri.n_pred[k]):
+            fa.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            fb.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            ip += 1
+        sta, Ka = fa.update(ri.pos[k], ri.quat[k], ri.notch[k], want_gain=True)
+        stb, Kb = fb.update(ri.pos[k], ri.quat[k], ri.notch[k], want_gain=True)
+        assert torch.equal(sta, stb)
+        a, b = fa.get_state(), fb.get_state()
+        for key in ("x", "P"):
+            scale = a[key].abs().amax(dim=tuple(range(1, a[key].dim())), keepdim=True)
+            assert float(((a[key] - b[key]).abs() / scale).max()) < 1e-12, (k, key)
+        kscale = Ka.abs().amax(dim=(1, 2), keepdim=True)
+        assert float(((Ka - Kb).abs() / kscale).max()) < 1e-11, k
+
+
+@pytest.mark.parametrize("lpi", [1, 32])
+def test_singular_innovation_sets_status_and_leaves_state(lpi):
     """Filter.py:356-361: LinAlgError path -> no change, no exception."""
     B = 5
     cfg, ri, Q, R, sa, so = default_run(golden_compat=True)
-    f = _make(cfg, ri, Q, np.zeros((7, 7)), sa, so, B, True)
+    f = _make(cfg, ri, Q, np.zeros((7, 7)), sa, so, B, True, lpi=lpi)
     P0 = np.tile(ri.P0, (B, 1, 1))
     P0[1] = 0.0
     P0[3] = 0.0
