@@ -357,12 +357,14 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
         J.Em[3] = -hs[2]; J.Em[4] = T(1);   J.Em[5] = hs[0];
         J.Em[6] = hs[1];  J.Em[7] = -hs[0]; J.Em[8] = T(1);
         // noise Jacobian camera rows (only needed when the gyro block of Q is non-zero)
-        T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
-        mat3_skew(Ro, dp, J.N6);
+        if (prm.q_gyro) {   // (without it the record ends after dt: the caller's staging rows are 67 words)
+            T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
+            mat3_skew(Ro, dp, J.N6);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
+                for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
+        }
     }
     // buffer swap (Filter.py:225-227)
 #pragma unroll
@@ -424,15 +426,18 @@ __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const S
 // (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
 template <typename T>
-__global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
+__global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
     // Two wavefronts per block work on the same 64 instances: wave 0 propagates the nominal state
     // (and forms the residual), wave 1 forms the Jacobian blocks.  Both read the state before wave 0
     // overwrites it (block barrier).  Wave 1 stages its 67-word records in LDS (row stride 69:
     // conflict-free) and writes them out as whole records with 16-byte stores -- a lane-per-instance
     // store of an array-of-structures would touch 64 different cache lines per instruction.
-    constexpr int JS = 85;                             // = sizeof(Jac<T>) / sizeof(T): odd -> conflict-free
-    static_assert(sizeof(Jac<T>) == JS * sizeof(T), "Jac<T> must be the 85-word record");
-    __shared__ __attribute__((aligned(16))) T sJ[64 * JS];
+    static_assert(sizeof(Jac<T>) == J_FULL * sizeof(T), "Jac<T> must be the 85-word record");
+    // staging rows of 85 words, or 67 when the gyro block of Q is zero and the N6 block is not formed
+    // (both odd -> conflict-free); sized by the launcher: 34 KB lets four blocks share a CU
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sJ = reinterpret_cast<T*>(smem_raw);
+    const int JS = prm.q_gyro ? J_FULL : J_CORE;
     const int lane = threadIdx.x & 63;
     const bool jac_role = threadIdx.x >= 64;           // wave-uniform
     const int64_t b0 = (int64_t)blockIdx.x * 64;
@@ -451,16 +456,16 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
     __syncthreads();                               // every read of the old state (and of the pending
                                                    // error state) precedes this step's writes
     if (inject_now) inject_error(s, epend);        // the previous update's injection (both roles)
-    if (jac_role && a.n_pred == 0) return;
-    const int npiece = prm.q_gyro ? 43 : 34;       // 16-byte pieces of a record: 85 / 67 words
-    for (int ip = 0; ip < a.n_pred; ++ip) {
-        const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
-        const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
-        const T* gom = reinterpret_cast<const T*>(a.om) + so;
-        const T* gac = reinterpret_cast<const T*>(a.acc) + so;
-        const T dt = gdt[0];
-        T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
-        if (jac_role) {
+    if (jac_role) {
+        // ---- wave 1: Jacobian blocks of every predict of this launch ---------------------------
+        const int npiece = prm.q_gyro ? 43 : 34;   // 16-byte pieces of a record: 85 / 67 words
+        for (int ip = 0; ip < a.n_pred; ++ip) {
+            const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
+            const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
+            const T* gom = reinterpret_cast<const T*>(a.om) + so;
+            const T* gac = reinterpret_cast<const T*>(a.acc) + so;
+            const T dt = gdt[0];
+            T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
             // the blocks are written straight into this lane's staging row (the struct IS the record),
             // so they do not occupy registers; only this wavefront touches sJ: wave-level ordering
             Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
@@ -482,12 +487,21 @@ __global__ __launch_bounds__(128) void eskf_pre_kernel(StepArgs a, DevParams<T> 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        } else {
-            Jac<T> J;
-            predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
         }
+        return;
     }
-    if (jac_role || !live) return;
+    // ---- wave 0: nominal state through every predict, then the residual -------------------------
+    for (int ip = 0; ip < a.n_pred; ++ip) {
+        const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
+        const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
+        const T* gom = reinterpret_cast<const T*>(a.om) + so;
+        const T* gac = reinterpret_cast<const T*>(a.acc) + so;
+        const T dt = gdt[0];
+        T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
+        Jac<T> J;
+        predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
+    }
+    if (!live) return;
     if (a.do_update) {
         // measurement correction and residual (Filter.py:364-375)
         const int64_t mo = a.meas_stride ? b : 0;
@@ -978,6 +992,20 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
 //            other lanes' column results by symmetry
 // The Jacobian record is read from LDS with group-uniform (broadcast) addresses.
 // ----------------------------------------------------------------------------------
+// 1/x by v_rcp + two Newton steps (5 dependent operations instead of the 11 of the IEEE division
+// sequence; the result is within an ulp or two, and only ever multiplies: pivots of S = L D L^T)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    r = fmaf(fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+
 namespace rowk {
 // exchange image: row stride PS = 25 (conflict-free row writes and column reads)
 constexpr int XS = 10;             // row stride of the 24 x 7 panels: 16-byte aligned rows, 2-way bank conflicts at most
@@ -1217,7 +1245,7 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                 for (int k = 0; k < j; ++k) dj -= Lm[j * (j - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
                 d[j] = dj;
                 ok = ok && (dj != T(0)) && t_finite(dj);
-                rd[j] = T(1) / dj;
+                rd[j] = fast_rcp(dj);
 #pragma unroll
                 for (int i = j + 1; i < 7; ++i) {
                     T v = S[i * (i + 1) / 2 + j];
@@ -1234,9 +1262,20 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
         status = ok ? 0 : DVI_STATUS_SINGULAR;
         if (gres[7] != T(0)) status |= DVI_STATUS_NONFINITE;
 
-        // ---- Z[i,:] L^T = P[i,sel]; K[i,:] = (Z D^-1) L^-1; e_i = K[i,:] res -------------------
+        // ---- Z[i,:] L^T = P[i,sel]; e_i = K[i,:] res with K = Z D^-1 L^-1, evaluated as
+        // (Z D^-1)[i,:] (L^-1 res): the triangular solve on the residual does not depend on the
+        // lane's row, so it stays off the critical path.  K itself only when it is asked for.
         if (ok) {
-            T k[7];
+            T tr[7];                        // D^-1 L^-1 res (group-uniform)
+#pragma unroll
+            for (int m = 0; m < 7; ++m) {
+                T v = res[m];
+#pragma unroll
+                for (int n = 0; n < m; ++n) v -= tr[n] * Lm[m * (m - 1) / 2 + n];
+                tr[m] = v;
+            }
+#pragma unroll
+            for (int m = 0; m < 7; ++m) tr[m] *= rd[m];
 #pragma unroll
             for (int m = 0; m < 7; ++m) {
                 T v = p[sel[m]];
@@ -1244,16 +1283,9 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                 for (int n = 0; n < m; ++n) v -= z[n] * Lm[m * (m - 1) / 2 + n];
                 z[m] = v;
             }
-#pragma unroll
-            for (int m = 6; m >= 0; --m) {
-                T v = z[m] * rd[m];
-#pragma unroll
-                for (int n = m + 1; n < 7; ++n) v -= k[n] * Lm[n * (n - 1) / 2 + m];
-                k[m] = v;
-            }
             T e = T(0);
 #pragma unroll
-            for (int m = 0; m < 7; ++m) e += k[m] * res[m];
+            for (int m = 0; m < 7; ++m) e += z[m] * tr[m];
             if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
             if (active) {
 #pragma unroll
@@ -1262,6 +1294,14 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                 if (valid) {
                     reinterpret_cast<T*>(a.e)[inst * 24 + row] = e;
                     if (a.K_out) {
+                        T k[7];
+#pragma unroll
+                        for (int m = 6; m >= 0; --m) {
+                            T v = z[m] * rd[m];
+#pragma unroll
+                            for (int n = m + 1; n < 7; ++n) v -= k[n] * Lm[n * (n - 1) / 2 + m];
+                            k[m] = v;
+                        }
                         T* gK = reinterpret_cast<T*>(a.K_out) + (inst * 24 + row) * 7;
 #pragma unroll
                         for (int m = 0; m < 7; ++m) gK[m] = k[m];
@@ -1469,7 +1509,8 @@ template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), 0, stream, a, prm);
+    const size_t stage_bytes = (size_t)64 * (prm.q_gyro ? J_FULL : J_CORE) * sizeof(T);
+    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 2. covariance: LPI lanes per instance

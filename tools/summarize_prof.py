@@ -18,7 +18,7 @@ res = {"tag": tag}
 if trace:
     allrows = list(csv.DictReader(open(trace[0])))
     res["step_kernels"] = {}
-    for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_post_kernel"):
+    for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_cov_rows_kernel", "eskf_post_kernel"):
         t = [r for r in allrows if key in r["Kernel_Name"]]
         if not t:
             continue
@@ -42,7 +42,7 @@ if len(sys.argv) >= 5:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         pm[name] = {}
         for k, v in acc.items():
-            for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_post_kernel"):
+            for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_cov_rows_kernel", "eskf_post_kernel"):
                 if key in k:
                     pm[name][key] = {"launches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}
             if "copyBuffer" in k:
