@@ -986,8 +986,10 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
 //   predict  P' = Fx P Fx^T as two applications of v -> Fx v: lane i computes (Fx P)[:,i] and
 //            writes it as row i of W = P Fx^T; lane j reads column j of W and applies Fx again,
 //            which leaves row j of P' in its registers.  One 24x24 transposition per predict.
-//   update   every lane publishes P[i,sel] (7 words): rows sel of that panel are S; the same panel
-//            then carries Z = P H^T L^-T for the rank-7 downdate P[i,:] -= (Z D^-1)[i,:] Z^T
+//   update   the 7 measurements are processed one after the other (R is diagonal, so this is the
+//            joint update of Filter.py:351-385 with S = L D L^T factorised on the fly: the scalar
+//            innovation variances are the pivots D): every lane publishes P[i][sel_m], reads the
+//            column back and applies the rank-1 downdate to its row
 //   reset    G P G^T: column part in registers; the six rows it touches are gathered from the
 //            other lanes' column results by symmetry
 // The Jacobian record is read from LDS with group-uniform (broadcast) addresses.
@@ -1008,13 +1010,13 @@ __device__ __forceinline__ float fast_rcp(float x) {
 
 namespace rowk {
 // exchange image: row stride PS = 25 (conflict-free row writes and column reads)
-constexpr int XS = 10;             // row stride of the 24 x 7 panels: 16-byte aligned rows, 2-way bank conflicts at most
-constexpr int R_BUF = 0;         // 24 x 25 exchange image | [24][XS] panel of the reset
-constexpr int R_X = 600;         // [24][XS]: P[:,sel], then Z
-constexpr int R_E = 840;         // 24 error-state words
-constexpr int R_J = 864;         // Jacobian record, blocks re-laid on even offsets (16-byte reads)
+constexpr int XS = 10;             // row stride of the [24][6] panel of the reset (16-byte rows, <= 2-way conflicts)
+constexpr int R_BUF = 0;           // 24 x 25 exchange image | [24][XS] panel of the reset
+constexpr int R_C = 600;           // two 24-word column buffers (alternating)
+constexpr int R_J = 648;           // Jacobian record, blocks re-laid on even offsets (16-byte reads)
 constexpr int L_A = 0, L_TH = 10, L_BM = 20, L_CM = 30, L_DM = 48, L_EM = 60, L_DT = 70, L_N6 = 72;
-constexpr int R_REGION = 954;        // words per instance (even)
+constexpr int R_RES = 744;         // residual of the update (7) + non-finite flag
+constexpr int R_REGION = 752;      // words per instance (even)
 __device__ __forceinline__ int lds_word(int e) {   // HBM record word -> LDS word
     return e + (e >= J_TH) + (e >= J_BM) + (e >= J_CM) + (e >= J_DT) + (e >= J_N6);
 }
@@ -1077,10 +1079,201 @@ __device__ __forceinline__ void fx_apply(const T* sJ, const T (&v)[24], T (&o)[2
         o[21 + r] = w;
     }
 }
+// dst[0:24] = Fx v (v in registers), written out piece by piece so that neither the outputs nor the
+// Jacobian blocks of the later pieces pile up in registers
+template <typename T>
+__device__ __forceinline__ void fx_apply_store(const T* sJ, const T (&v)[24], T* dst, bool active) {
+    const T dt = sJ[L_DT];
+    {
+        T A[9], Th[9], o[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { A[k] = sJ[L_A + k]; Th[k] = sJ[L_TH + k]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[r] = v[r] + dt * v[3 + r];
+            o[3 + r] = v[3 + r] + A[3 * r] * v[6] + A[3 * r + 1] * v[7] + A[3 * r + 2] * v[8];
+            o[6 + r] = Th[3 * r] * v[6] + Th[3 * r + 1] * v[7] + Th[3 * r + 2] * v[8];
+        }
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = o[k];
+#pragma unroll
+            for (int k = 9; k < 15; ++k) dst[k] = v[k];
+            dst[15] = v[15] + dt * v[16];
+            dst[16] = v[16] + dt * v[17];
+            dst[17] = v[17];
+        }
+    }
+    asm volatile("" : : : "memory");
+    {
+        T o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T Bm[3], Cm[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Bm[k] = sJ[L_BM + 3 * r + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Cm[k] = sJ[L_CM + 6 * r + k];
+            T u = dt * v[3 + r] + v[16 + r];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) u += Bm[k] * v[6 + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u += Cm[k] * v[9 + k];
+            o[r] = u;
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dst[18 + r] = o[r];
+        }
+    }
+    asm volatile("" : : : "memory");
+    {
+        T o[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T Dm[4], Em[3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Dm[k] = sJ[L_DM + 4 * r + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Em[k] = sJ[L_EM + 3 * r + k];
+            T w = Dm[3] * v[15];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w += Dm[k] * v[9 + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w += Em[k] * v[19 + k];
+            if (r == 1) w += v[22];
+            if (r == 2) w += v[23];
+            o[r] = w;
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dst[21 + r] = o[r];
+        }
+    }
+}
+
+// o = Fx c for the column c[k] = col[k * PS] of the exchange image, read in three pieces so that
+// at most nine inputs are live next to the outputs (the camera rows 18:24 are accumulated)
+template <typename T>
+__device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[24]) {
+    const T dt = sJ[L_DT];
+    T u[3], w[3];
+    {   // inputs 0..8
+        T c[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k] = col[k * PS];
+        T A[9], Th[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { A[k] = sJ[L_A + k]; Th[k] = sJ[L_TH + k]; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            o[r] = c[r] + dt * c[3 + r];
+            o[3 + r] = c[3 + r] + A[3 * r] * c[6] + A[3 * r + 1] * c[7] + A[3 * r + 2] * c[8];
+            o[6 + r] = Th[3 * r] * c[6] + Th[3 * r + 1] * c[7] + Th[3 * r + 2] * c[8];
+            T Bm[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Bm[k] = sJ[L_BM + 3 * r + k];
+            T x = dt * c[3 + r];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x += Bm[k] * c[6 + k];
+            u[r] = x;
+        }
+    }
+    asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]) : : "memory");
+    {   // inputs 9..17
+        T c[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k] = col[(9 + k) * PS];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[9 + k] = c[k];
+        o[15] = c[6] + dt * c[7];
+        o[16] = c[7] + dt * c[8];
+        o[17] = c[8];
+        u[0] += c[7];                       // c[16 + r], r = 0, 1 (r = 2 is input 18)
+        u[1] += c[8];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T Cm[6], Dm[4];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Cm[k] = sJ[L_CM + 6 * r + k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Dm[k] = sJ[L_DM + 4 * r + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) u[r] += Cm[k] * c[k];
+            T y = Dm[3] * c[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) y += Dm[k] * c[k];
+            w[r] = y;
+        }
+    }
+    asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : : "memory");
+    {   // inputs 18..23
+        T c[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = col[(18 + k) * PS];
+        u[2] += c[0];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            T Em[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) Em[k] = sJ[L_EM + 3 * r + k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[r] += Em[k] * c[1 + k];
+        }
+        w[1] += c[4];
+        w[2] += c[5];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[18 + r] = u[r]; o[21 + r] = w[r]; }
+}
+
+// P' += Fi Q Fi^T on the row-resident P: diagonal entries 3..14 <- Q[i-3], 17 <- Q[12]
+// (Filter.py:263-264,349); with gyro noise (tune mode) also the camera rows through N6 and theta
+// through Fi[6:9,3:6] = I
+template <typename T>
+__device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, int row, T (&p)[24]) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? prm.qd[k] : T(0);
+    p[17] += (row == 17) ? prm.qd[12] : T(0);
+    if (prm.q_gyro) {
+        const T* N6 = sJ + L_N6;
+        if (row >= 18) {
+            const int ar = row - 18;
+            T na[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                na[k] = N6[3 * ar + k] * prm.qd[3 + k];
+                p[6 + k] += na[k];
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p[18 + b] += na[k] * N6[3 * b + k];
+        } else if (row >= 6 && row < 9) {
+            const int k = row - 6;
+            const T qk = (k == 0) ? prm.qd[3] : (k == 1) ? prm.qd[4] : prm.qd[5];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) p[18 + b] += N6[3 * b + k] * qk;
+        }
+    }
+}
+
+// scheduling fence: every element of the row is final before anything after it is issued
+template <typename T>
+__device__ __forceinline__ void pin_row(T (&p)[24]) {
+    asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                      "+v"(p[8]), "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]),
+                      "+v"(p[16]), "+v"(p[17]), "+v"(p[18]), "+v"(p[19]), "+v"(p[20]), "+v"(p[21]), "+v"(p[22]), "+v"(p[23])
+                 : : "memory");
+}
 }  // namespace rowk
 
+// waves per SIMD the row-resident kernel is built for: 3 (<= 168 VGPRs; it needs 162)
+#ifndef ROWS_WAVES
+#define ROWS_WAVES 3
+#endif
 template <typename T>
-__global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
+__global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     using namespace rowk;
     constexpr int LPI = 32, G = 2;
     __shared__ __attribute__((aligned(16))) T smem[G * R_REGION];
@@ -1092,266 +1285,198 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
     const int row0 = active ? lig : 23;     // idle lanes shadow row 23 and write nothing
 
     T* sB = smem + grp * R_REGION + R_BUF;
-    T* sX = smem + grp * R_REGION + R_X;
-    T* sE = smem + grp * R_REGION + R_E;
+    T* sC = smem + grp * R_REGION + R_C;
     T* sJ = smem + grp * R_REGION + R_J;
+    T* sR = smem + grp * R_REGION + R_RES;
 
     const int jwords = prm.q_gyro ? J_FULL : J_CORE;
     constexpr int NJ = (J_FULL + LPI - 1) / LPI;
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
 
-    const int64_t round_stride = (int64_t)gridDim.x * G;
-    const int64_t slot = (int64_t)blockIdx.x * G + grp;
+    // instance indices are 32-bit (the launcher refuses B >= 2^31) and made opaque once per round:
+    // byte addresses are formed where they are used instead of being carried as 64-bit induction
+    // variables through the round
+    const int nB = (int)a.B;
+    const int round_stride = (int)gridDim.x * G;
+    const int slot = (int)blockIdx.x * G + grp;
     T2 pv[NV];
-    T jv[NJ];
 #define ESKF_ISSUE_LOADS(INST)                                                                     \
-    {                                                                                              \
-        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P) + (INST) * 300); \
+    {   /* (no predicates: the last piece is fetched twice by the lanes beyond the record) */       \
+        int lp_ = lig;                                                                             \
+        asm volatile("" : "+v"(lp_));                                                              \
+        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P) + (int64_t)(INST) * 300); \
         _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
-            const int e2 = lig + k * LPI;                                                          \
-            if (e2 < 150) pv[k] = gP2_[e2];                                                        \
-        }                                                                                          \
-        if (a.n_pred > 0) {                                                                        \
-            const T* gJ_ = reinterpret_cast<const T*>(a.J) + (INST) * JW;                          \
-            _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                       \
-                const int e = lig + k * LPI;                                                       \
-                if (e < jwords) jv[k] = gJ_[e];                                                    \
-            }                                                                                      \
+            const int e2 = lp_ + k * LPI;                                                          \
+            pv[k] = gP2_[e2 < 150 ? e2 : 149];                                                     \
         }                                                                                          \
     }
-    {
-        const int64_t i0 = slot < a.B ? slot : a.B - 1;
+    // Jacobian record IP of instance INST and the residual of the update -> registers -> LDS.  No
+    // predicates either: every lane moves three record words (the 88-word record is padded; what
+    // lies beyond the blocks in use lands in the idle N6 area) and one residual word.
+#define ESKF_LOAD_J(DST, RES, INST, IP)                                                            \
+    {                                                                                              \
+        int lj_ = lig;                                                                             \
+        asm volatile("" : "+v"(lj_));   /* (per-lane addresses formed here, not kept across rounds) */ \
+        const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
+        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
+            const int w = lj_ + k * LPI;                                                           \
+            DST[k] = gJ_[w < JW ? w : JW - 1];                                                     \
+        }                                                                                          \
+        RES = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                  \
+    }
+#define ESKF_STAGE_J(SRC, RES)                                                                     \
+    {                                                                                              \
+        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
+            const int w = lig + k * LPI;                                                           \
+            sJ[lds_word(w < JW ? w : JW - 1)] = SRC[k];                                            \
+        }                                                                                          \
+        sR[lig & 7] = RES;                                                                         \
+    }
+    // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
+#define ESKF_UNPACK_ROW()                                                                          \
+    {                                                                                              \
+        int lg_ = lig;                                                                             \
+        asm volatile("" : "+v"(lg_));   /* (recomputed per use, not carried in registers) */       \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
+            const int e2r = lg_ + k * LPI, e2 = e2r < 150 ? e2r : 149;                             \
+            int i, j;                                                                              \
+            unpack_ij(2 * e2, i, j);                                                               \
+            sB[i * PS + j] = pv[k].x;                                                              \
+            unpack_ij(2 * e2 + 1, i, j);                                                           \
+            sB[i * PS + j] = pv[k].y;                                                              \
+        }                                                                                          \
+        group_sync();                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[(j <= row) ? row * PS + j : j * PS + row]; \
+        group_sync();                                                                              \
+    }
+    // one predict on the row-resident P with the Jacobian record that sits in LDS
+#define ESKF_PREDICT_ROWS()                                                                        \
+    {                                                                                              \
+        fx_apply_store(sJ, p, sB + row * PS, active);   /* column `row` of Fx P = row `row` of W = P Fx^T */ \
+        group_sync();                                                                              \
+        fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */          \
+        noise_rows(prm, sJ, row, p);                                                               \
+        group_sync();                                                                              \
+    }
+    {   // first instance of this wave: packed covariance into registers, first records into LDS
+        const int i0 = slot < nB ? slot : nB - 1;
         ESKF_ISSUE_LOADS(i0)
+        T j0[NJ], r0 = T(0);
+        ESKF_LOAD_J(j0, r0, i0, 0)
+        ESKF_STAGE_J(j0, r0)
     }
 
   for (int rnd = 0; rnd < a.rounds; ++rnd) {
-    const int64_t inst_raw = (int64_t)rnd * round_stride + slot;
-    const bool valid = inst_raw < a.B;      // tail: recompute the last instance, write nothing
-    const int64_t inst = valid ? inst_raw : a.B - 1;
-    T* gP = reinterpret_cast<T*>(a.P) + inst * 300;
-    int row = row0;
-    asm volatile("" : "+v"(row));           // per-lane addresses are recomputed per round, not kept in registers
+    const int inst_raw = rnd * round_stride + slot;
+    const bool valid = inst_raw < nB;       // tail: recompute the last instance, write nothing
+    int inst = valid ? inst_raw : nB - 1;
+    int row = row0;                         // per-lane addresses are recomputed per round, not kept in registers
+    asm volatile("" : "+v"(row), "+v"(inst));
 
-    // ---- packed record -> lower-triangle image; Jacobian record -> LDS ------------------------
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int e2 = lig + k * LPI;
-        if (e2 < 150) {
-            int i, j;
-            unpack_ij(2 * e2, i, j);
-            sB[i * PS + j] = pv[k].x;
-            unpack_ij(2 * e2 + 1, i, j);
-            sB[i * PS + j] = pv[k].y;
-        }
-    }
-    if (a.n_pred > 0) {
-#pragma unroll
-        for (int k = 0; k < NJ; ++k) {
-            const int e = lig + k * LPI;
-            if (e < jwords) sJ[lds_word(e)] = jv[k];
-        }
-    }
-    group_sync();
+    constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
     T p[24];                                // row `row` of P
-#pragma unroll
-    for (int j = 0; j < 24; ++j) p[j] = sB[(j <= row) ? row * PS + j : j * PS + row];
-    group_sync();
+    ESKF_UNPACK_ROW()
 
     // ================================ predict(s) =======================================
     for (int ip = 0; ip < a.n_pred; ++ip) {
-        if (ip > 0) {
-            const T* gJ = reinterpret_cast<const T*>(a.J) + ((int64_t)ip * a.B + inst) * JW;
-            T jn[NJ];
-#pragma unroll
-            for (int k = 0; k < NJ; ++k) {
-                const int e = lig + k * LPI;
-                if (e < jwords) jn[k] = gJ[e];
-            }
-#pragma unroll
-            for (int k = 0; k < NJ; ++k) {
-                const int e = lig + k * LPI;
-                if (e < jwords) sJ[lds_word(e)] = jn[k];
-            }
+        if (ip > 0) {                       // (the first record was staged at the end of the previous round)
+            T jn[NJ], rn = T(0);
+            ESKF_LOAD_J(jn, rn, inst, ip)
+            ESKF_STAGE_J(jn, rn)
             group_sync();
         }
-        {
-            T o[24];
-            fx_apply(sJ, p, o);             // column `row` of Fx P = row `row` of W = P Fx^T
-            if (active) {
-#pragma unroll
-                for (int l = 0; l < 24; ++l) sB[row * PS + l] = o[l];
-            }
-        }
-        group_sync();
-        {
-            T c[24];
-#pragma unroll
-            for (int k = 0; k < 24; ++k) c[k] = sB[k * PS + row];
-            fx_apply(sJ, c, p);             // column `row` of Fx P Fx^T = row `row` of P'
-        }
-        // Fi Q Fi^T: diagonal entries 3..14 <- Q[i-3], 17 <- Q[12]  (Filter.py:263-264,349)
-#pragma unroll
-        for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? prm.qd[k] : T(0);
-        p[17] += (row == 17) ? prm.qd[12] : T(0);
-        if (prm.q_gyro) {   // gyro noise reaches the camera rows through N6 and theta through Fi[6:9,3:6] = I
-            const T* N6 = sJ + L_N6;
-            if (row >= 18) {
-                const int ar = row - 18;
-                T na[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    na[k] = N6[3 * ar + k] * prm.qd[3 + k];
-                    p[6 + k] += na[k];
-                }
-#pragma unroll
-                for (int b = 0; b < 6; ++b)
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) p[18 + b] += na[k] * N6[3 * b + k];
-            } else if (row >= 6 && row < 9) {
-                const int k = row - 6;
-                const T qk = (k == 0) ? prm.qd[3] : (k == 1) ? prm.qd[4] : prm.qd[5];
-#pragma unroll
-                for (int b = 0; b < 6; ++b) p[18 + b] += N6[3 * b + k] * qk;
-            }
-        }
-        group_sync();
+        ESKF_PREDICT_ROWS()
     }
 
     // ================================ update ===========================================
-    constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
-    T z[7], rd[7];
-    bool ok = false;
+    // The 7 measurements one after the other; sv is the pivot d_m of S = L D L^T.  A zero or
+    // non-finite pivot is the reference's LinAlgError (Filter.py:356-361: nothing changes): the
+    // remaining measurements are skipped and the ones already applied are taken back.
+    T e = T(0);                             // component `row` of the error state
     int status = 0;
+    bool fail = false;
     if (a.do_update) {
-        if (active) {
+        status = (sR[7] != T(0)) ? DVI_STATUS_NONFINITE : 0;
+        T E[7];                             // error estimate at the measured components (group-uniform)
 #pragma unroll
-            for (int m = 0; m < 7; ++m) sX[row * XS + m] = p[sel[m]];
+        for (int m = 0; m < 7; ++m) E[m] = T(0);
+        int napplied = 0;
+#pragma unroll
+        for (int m = 0; m < 7; ++m) {
+            T* cb = sB + m * 24;            // (the exchange image is idle during the update; the columns
+                                            //  stay there for the take-back)
+            const T pm = p[sel[m]];
+            if (active) cb[row] = pm;       // column sel_m of the current P
+            group_sync();
+            // upper half of the column first: it holds the measured components
+            T c[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) c[j] = cb[12 + j];
+            const T sv = c[sel[m] - 12] + prm.r[m];
+            fail = fail || !(sv != T(0) && t_finite(sv));
+            if (!fail) {
+                const T g = T(1) / sv;
+                const T tau = (sR[m] - E[m]) * g;
+                const T kk = pm * g;        // gain of this measurement, component `row`
+                e += pm * tau;
+#pragma unroll
+                for (int m2 = m + 1; m2 < 7; ++m2) E[m2] += c[sel[m2] - 12] * tau;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) p[12 + j] -= kk * c[j];   // Joseph form with the optimal gain, Filter.py:383-384
+                asm volatile("" : : : "memory");
+#pragma unroll
+                for (int j = 0; j < 12; ++j) c[j] = cb[j];
+#pragma unroll
+                for (int j = 0; j < 12; ++j) p[j] -= kk * c[j];
+                napplied = m + 1;
+            }
+            // one measurement at a time: without these fences the scheduler runs ahead along the
+            // pivot chain and parks seven columns in scratch for the deferred row updates
+            pin_row(p);
+            asm volatile("" : "+v"(e), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
         }
-        group_sync();
-        // ---- S = H P H^T + R = rows sel of the panel; LDL^T, redundantly in every lane ---------
-        T Lm[21], d[7];          // unit-lower L packed by rows: L[i][j] at i(i-1)/2 + j
-        ok = true;
-        {
-            T S[28];
+        if (__builtin_expect(fail, 0)) {
+            // take the applied measurements back, last first (the predicted covariance is restored
+            // to rounding; bit-exact when the first pivot fails, e.g. P = 0 and R = 0)
+            status |= DVI_STATUS_SINGULAR;
 #pragma unroll
-            for (int i = 0; i < 7; ++i)
+            for (int m = 6; m >= 0; --m) {
+                if (m < napplied) {
+                    const T* cb = sB + m * 24;
+                    const T g = T(1) / (cb[sel[m]] + prm.r[m]);
+                    const T kk = cb[row] * g;
 #pragma unroll
-                for (int j = 0; j <= i; ++j) S[i * (i + 1) / 2 + j] = sX[sel[i] * XS + j] + (i == j ? prm.r[i] : T(0));
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                T dj = S[j * (j + 1) / 2 + j];
-#pragma unroll
-                for (int k = 0; k < j; ++k) dj -= Lm[j * (j - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
-                d[j] = dj;
-                ok = ok && (dj != T(0)) && t_finite(dj);
-                rd[j] = fast_rcp(dj);
-#pragma unroll
-                for (int i = j + 1; i < 7; ++i) {
-                    T v = S[i * (i + 1) / 2 + j];
-#pragma unroll
-                    for (int k = 0; k < j; ++k) v -= Lm[i * (i - 1) / 2 + k] * Lm[j * (j - 1) / 2 + k] * d[k];
-                    Lm[i * (i - 1) / 2 + j] = v * rd[j];
+                    for (int j = 0; j < 24; ++j) p[j] += kk * cb[j];
+                    pin_row(p);
                 }
             }
         }
-        const T* gres = reinterpret_cast<const T*>(a.res) + inst * 8;
-        T res[7];
-#pragma unroll
-        for (int m = 0; m < 7; ++m) res[m] = gres[m];
-        status = ok ? 0 : DVI_STATUS_SINGULAR;
-        if (gres[7] != T(0)) status |= DVI_STATUS_NONFINITE;
+    }
 
-        // ---- Z[i,:] L^T = P[i,sel]; e_i = K[i,:] res with K = Z D^-1 L^-1, evaluated as
-        // (Z D^-1)[i,:] (L^-1 res): the triangular solve on the residual does not depend on the
-        // lane's row, so it stays off the critical path.  K itself only when it is asked for.
-        if (ok) {
-            T tr[7];                        // D^-1 L^-1 res (group-uniform)
-#pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                T v = res[m];
-#pragma unroll
-                for (int n = 0; n < m; ++n) v -= tr[n] * Lm[m * (m - 1) / 2 + n];
-                tr[m] = v;
-            }
-#pragma unroll
-            for (int m = 0; m < 7; ++m) tr[m] *= rd[m];
-#pragma unroll
-            for (int m = 0; m < 7; ++m) {
-                T v = p[sel[m]];
-#pragma unroll
-                for (int n = 0; n < m; ++n) v -= z[n] * Lm[m * (m - 1) / 2 + n];
-                z[m] = v;
-            }
-            T e = T(0);
-#pragma unroll
-            for (int m = 0; m < 7; ++m) e += z[m] * tr[m];
-            if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
-            if (active) {
-#pragma unroll
-                for (int m = 0; m < 7; ++m) sX[row * XS + m] = z[m];
-                sE[row] = e;
-                if (valid) {
-                    reinterpret_cast<T*>(a.e)[inst * 24 + row] = e;
-                    if (a.K_out) {
-                        T k[7];
-#pragma unroll
-                        for (int m = 6; m >= 0; --m) {
-                            T v = z[m] * rd[m];
-#pragma unroll
-                            for (int n = m + 1; n < 7; ++n) v -= k[n] * Lm[n * (n - 1) / 2 + m];
-                            k[m] = v;
-                        }
-                        T* gK = reinterpret_cast<T*>(a.K_out) + (inst * 24 + row) * 7;
-#pragma unroll
-                        for (int m = 0; m < 7; ++m) gK[m] = k[m];
-                    }
-                }
-            }
-        }
-    }
-    // the next round's record is fetched while the rank-7 update, the reset and the store run
-    // (issued here, not earlier: the factorisation above needs the registers)
-    if (rnd + 1 < a.rounds) {
-        const int64_t nraw = (int64_t)(rnd + 1) * round_stride + slot;
-        const int64_t ni = nraw < a.B ? nraw : a.B - 1;
-        ESKF_ISSUE_LOADS(ni)
-    }
     if (a.do_update) {
+        const bool upd = !fail;
+        if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
+        if (upd && active) {
+            sC[row] = e;
+            if (valid) reinterpret_cast<T*>(a.e)[(int64_t)inst * 24 + row] = e;
+        }
         group_sync();
         T* sY = sB;     // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
-        if (ok) {
-            // ---- P[i,:] -= (Z D^-1)[i,:] Z^T (Joseph form with the optimal gain, Filter.py:383-384)
-            T zd[7];
-#pragma unroll
-            for (int m = 0; m < 7; ++m) zd[m] = z[m] * rd[m];
-#pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                T zj[7];
-#pragma unroll
-                for (int m = 0; m < 7; ++m) zj[m] = sX[j * XS + m];
-                T v = p[j];
-#pragma unroll
-                for (int m = 0; m < 7; ++m) v -= zj[m] * zd[m];
-                p[j] = v;
-                // finish four columns before the panel reads of the next four are issued (otherwise
-                // the scheduler front-loads all 168 panel words and spills)
-                if ((j & 3) == 3) asm volatile("" : "+v"(p[j - 3]), "+v"(p[j - 2]), "+v"(p[j - 1]), "+v"(p[j]) : : "memory");
-            }
+        if (upd) {
             // ---- reset G P G^T (Filter.py:387-390), G = I - [theta/2]x on 6:9 and 21:24.
             // column part, in registers
-            const T Gt[3] = {T(0.5) * sE[6], T(0.5) * sE[7], T(0.5) * sE[8]};
-            const T Gc[3] = {T(0.5) * sE[21], T(0.5) * sE[22], T(0.5) * sE[23]};
-            {
-                const T a0 = p[6], a1 = p[7], a2 = p[8];
-                p[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
-                p[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
-                p[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
-                const T b0 = p[21], b1 = p[22], b2 = p[23];
-                p[21] = b0 + Gc[2] * b1 - Gc[1] * b2;
-                p[22] = b1 - Gc[2] * b0 + Gc[0] * b2;
-                p[23] = b2 + Gc[1] * b0 - Gc[0] * b1;
-            }
+            T Gt[3], Gc[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { Gt[k] = T(0.5) * sC[6 + k]; Gc[k] = T(0.5) * sC[21 + k]; }
+            const T a0 = p[6], a1 = p[7], a2 = p[8];
+            p[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
+            p[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
+            p[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
+            const T b0 = p[21], b1 = p[22], b2 = p[23];
+            p[21] = b0 + Gc[2] * b1 - Gc[1] * b2;
+            p[22] = b1 - Gc[2] * b0 + Gc[0] * b2;
+            p[23] = b2 + Gc[1] * b0 - Gc[0] * b1;
             if (active) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -1359,29 +1484,29 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
                     sY[row * XS + 4 + k] = p[21 + k];
                 }
             }
-            group_sync();
-            // row part: only rows 6:9 and 21:24 change.  For a column j outside those blocks
-            // P_new[i][j] = P_new[j][i], which lane j already holds (its column result); inside
-            // them the 3x3 row combination of the column results of the lane's own triple.
-            const bool lo = row >= 6 && row < 9, hi = row >= 21;
-            if (lo || hi) {
-                const int tb = lo ? 6 : 21;
-                const int t = row - tb;
-                const int sw = lo ? t : 4 + t;
-                const T g0 = lo ? Gt[0] : Gc[0], g1 = lo ? Gt[1] : Gc[1], g2 = lo ? Gt[2] : Gc[2];
-                const T k0 = (t == 0) ? T(1) : (t == 1) ? -g2 : g1;
-                const T k1 = (t == 0) ? g2 : (t == 1) ? T(1) : -g0;
-                const T k2 = (t == 0) ? -g1 : (t == 1) ? g0 : T(1);
-                const T* y0 = sY + tb * XS;
+        }
+        group_sync();
+        // row part: only rows 6:9 and 21:24 change.  For a column j outside those blocks
+        // P_new[i][j] = P_new[j][i], which lane j already holds (its column result); inside
+        // them the 3x3 row combination of the column results of the lane's own triple.
+        const bool lo = row >= 6 && row < 9, hi = row >= 21;
+        if (upd && (lo || hi)) {
+            const int tb = lo ? 6 : 21;
+            const int t = row - tb;
+            const int sw = lo ? t : 4 + t;
+            const T g0 = T(0.5) * sC[tb], g1 = T(0.5) * sC[tb + 1], g2 = T(0.5) * sC[tb + 2];   // (read again: not kept across)
+            const T k0 = (t == 0) ? T(1) : (t == 1) ? -g2 : g1;
+            const T k1 = (t == 0) ? g2 : (t == 1) ? T(1) : -g0;
+            const T k2 = (t == 0) ? -g1 : (t == 1) ? g0 : T(1);
+            const T* y0 = sY + tb * XS;
 #pragma unroll
-                for (int j = 0; j < 24; ++j) {
-                    const bool jl = j >= 6 && j < 9, jh = j >= 21;
-                    if (jl || jh) {
-                        const int sj = jl ? j - 6 : 4 + j - 21;
-                        p[j] = k0 * y0[sj] + k1 * y0[XS + sj] + k2 * y0[2 * XS + sj];
-                    } else {
-                        p[j] = sY[j * XS + sw];
-                    }
+            for (int j = 0; j < 24; ++j) {
+                const bool jl = j >= 6 && j < 9, jh = j >= 21;
+                if (jl || jh) {
+                    const int sj = jl ? j - 6 : 4 + j - 21;
+                    p[j] = k0 * y0[sj] + k1 * y0[XS + sj] + k2 * y0[2 * XS + sj];
+                } else {
+                    p[j] = sY[j * XS + sw];
                 }
             }
         }
@@ -1397,12 +1522,30 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
 #pragma unroll
         for (int j = 0; j < 24; ++j) sB[row * PS + j] = p[j];
     }
+    // the row is in LDS now: its registers take the next round's records (issued here, consumed at
+    // the top of the next round; the other waves of the SIMD cover the rest of the HBM latency)
+    asm volatile("" : : : "memory");        // (the loads below are not to be hoisted into the reset)
+    if (rnd + 1 < a.rounds) {
+        const int nraw = (rnd + 1) * round_stride + slot;
+        const int ni = nraw < nB ? nraw : nB - 1;
+        ESKF_ISSUE_LOADS(ni)
+        T jnext[NJ], rnext = T(0);
+        ESKF_LOAD_J(jnext, rnext, ni, 0)
+        ESKF_STAGE_J(jnext, rnext)          // (the Jacobian and residual areas are idle since the update)
+    } else {
+        // (defined on every path: otherwise the registers of the record consumed at the top of
+        // this round stay reserved through the whole round for the case that nothing is fetched)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { pv[k].x = T(0); pv[k].y = T(0); }
+    }
     group_sync();
     if (valid) {
-        T2* gP2 = reinterpret_cast<T2*>(gP);
+        T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
+        int lg2 = lig;                      // (recomputed, not carried through the round in registers)
+        asm volatile("" : "+v"(lg2));
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int e2 = lig + k * LPI;
+            const int e2 = lg2 + k * LPI;
             if (e2 < 150) {
                 int i, j;
                 T2 v;
@@ -1417,6 +1560,10 @@ __global__ __launch_bounds__(64, 2) void eskf_cov_rows_kernel(StepArgs a, DevPar
     group_sync();   // the next round overwrites the image
   }
 #undef ESKF_ISSUE_LOADS
+#undef ESKF_LOAD_J
+#undef ESKF_STAGE_J
+#undef ESKF_UNPACK_ROW
+#undef ESKF_PREDICT_ROWS
 }
 
 // ----------------------------------------------------------------------------------
@@ -1494,6 +1641,7 @@ static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipSt
 template <typename T>
 static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 2;
+    if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
     StepArgs b = a;
     int64_t blocks = (a.B + G - 1) / G;
     int rounds = 1;
@@ -1515,7 +1663,9 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (e != hipSuccess) return e;
     // 2. covariance: LPI lanes per instance
     switch (lpi) {
-        case 1:  e = launch_cov_rows<T>(a, prm, stream); break;    // DVI_ESKF_LANES_ROWS
+        case 1:  // DVI_ESKF_LANES_ROWS; the gain matrix is only formed by the LDS-image kernel
+            e = a.K_out ? launch_cov_t<T, 32>(a, prm, stream) : launch_cov_rows<T>(a, prm, stream);
+            break;
         case 64: e = launch_cov_t<T, 64>(a, prm, stream); break;
         case 32: e = launch_cov_t<T, 32>(a, prm, stream); break;
         case 24: e = launch_cov_t<T, 24>(a, prm, stream); break;

@@ -186,6 +186,7 @@ def test_fused_step_and_epoch_match_separate_launches():
     x0 = _perturbed_x0(ri, B)
     f1 = _make(cfg, ri, Q, R, sa, so, B, False, x0)
     f2 = f1.clone()
+    f2b = f1.clone()
     f3 = f1.clone()
     n = int(ri.n_pred[0])
     for i in range(n):
@@ -195,11 +196,14 @@ def test_fused_step_and_epoch_match_separate_launches():
     _close(f1.get_state(), f2.get_state())
     _close({"K": K1}, {"K": K2}, 1e-10)
     assert torch.equal(s1, s2)
-    # per-instance IMU stream laid out [n,B,...]
+    # per-instance IMU stream laid out [n,B,...] (bitwise against the broadcast stream through the
+    # same kernel: a gain request may be served by the other covariance kernel)
+    f2b.epoch(ri.dt[:n], ri.om[:n], ri.acc[:n], ri.pos[0], ri.quat[0], ri.notch[0])
+    _close(f2.get_state(), f2b.get_state())
     f5 = _make(cfg, ri, Q, R, sa, so, B, False, x0)
     f5.epoch(np.tile(ri.dt[:n, None], (1, B)), np.tile(ri.om[:n, None, :], (1, B, 1)),
              np.tile(ri.acc[:n, None, :], (1, B, 1)), ri.pos[0], ri.quat[0], ri.notch[0])
-    a, b = f2.get_state(), f5.get_state()
+    a, b = f2b.get_state(), f5.get_state()
     for key in a:
         assert torch.equal(a[key], b[key]), key
     # 1:1 pair
@@ -292,6 +296,31 @@ def test_singular_innovation_sets_status_and_leaves_state(lpi):
     after = f.get_state()
     for key in before:
         assert torch.equal(before[key][1], after[key][1]) and torch.equal(before[key][3], after[key][3])
+    assert not torch.equal(before["x"][0], after["x"][0])
+
+
+@pytest.mark.parametrize("lpi", [1, 32])
+def test_singular_after_first_pivot_restores_prediction(lpi):
+    """S singular although its first pivot is fine (R = 0, P[19,:] = 0 -> second pivot exactly 0): the
+    instance is left as it was (Filter.py:356-361).  The row-resident kernel has applied the first
+    measurement by then and takes it back: P is restored to rounding, the state is untouched."""
+    B = 4
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True)
+    f = _make(cfg, ri, Q, np.zeros((7, 7)), sa, so, B, True, lpi=lpi)
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((24, 24))
+    Pd = A @ A.T / 24 + np.eye(24)
+    P0 = np.tile(Pd, (B, 1, 1))
+    P0[2, 19, :] = 0.0
+    P0[2, :, 19] = 0.0
+    f.set_state(P=P0)
+    before = f.get_state()
+    st, _ = f.update(ri.pos[0], ri.quat[0], ri.notch[0])
+    assert list(st.cpu().numpy() & 1) == [0, 0, 1, 0]
+    after = f.get_state()
+    assert torch.equal(before["x"][2], after["x"][2])
+    dP = (before["P"][2] - after["P"][2]).abs().max() / before["P"][2].abs().max()
+    assert float(dP) <= (1e-14 if lpi == 1 else 0.0), float(dP)
     assert not torch.equal(before["x"][0], after["x"][0])
 
 
