@@ -1288,6 +1288,22 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     T* sC = smem + grp * R_REGION + R_C;
     T* sJ = smem + grp * R_REGION + R_J;
     T* sR = smem + grp * R_REGION + R_RES;
+    // where the words of the packed record live in the image: ten positions per lane (five 16-byte
+    // pieces of two words), worked out once per wave and read back each round -- the index
+    // arithmetic (a division by 25 per word) would otherwise be redone or carried in registers
+    constexpr int OS = 12;                  // table row stride (ints): 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) int sOff[LPI * OS];
+    if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int e2r = lig + k * LPI, e2 = e2r < 150 ? e2r : 149;
+            int i, j;
+            unpack_ij(2 * e2, i, j);
+            sOff[lig * OS + 2 * k] = i * PS + j;
+            unpack_ij(2 * e2 + 1, i, j);
+            sOff[lig * OS + 2 * k + 1] = i * PS + j;
+        }
+    }
 
     const int jwords = prm.q_gyro ? J_FULL : J_CORE;
     constexpr int NJ = (J_FULL + LPI - 1) / LPI;
@@ -1336,15 +1352,11 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
-        int lg_ = lig;                                                                             \
-        asm volatile("" : "+v"(lg_));   /* (recomputed per use, not carried in registers) */       \
+        int off_[2 * NV];                                                                          \
+        _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = sOff[lig * OS + k];           \
         _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
-            const int e2r = lg_ + k * LPI, e2 = e2r < 150 ? e2r : 149;                             \
-            int i, j;                                                                              \
-            unpack_ij(2 * e2, i, j);                                                               \
-            sB[i * PS + j] = pv[k].x;                                                              \
-            unpack_ij(2 * e2 + 1, i, j);                                                           \
-            sB[i * PS + j] = pv[k].y;                                                              \
+            sB[off_[2 * k]] = pv[k].x;                                                             \
+            sB[off_[2 * k + 1]] = pv[k].y;                                                         \
         }                                                                                          \
         group_sync();                                                                              \
         _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[(j <= row) ? row * PS + j : j * PS + row]; \
@@ -1416,7 +1428,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             const T sv = c[sel[m] - 12] + prm.r[m];
             fail = fail || !(sv != T(0) && t_finite(sv));
             if (!fail) {
-                const T g = T(1) / sv;
+                const T g = fast_rcp(sv);
                 const T tau = (sR[m] - E[m]) * g;
                 const T kk = pm * g;        // gain of this measurement, component `row`
                 e += pm * tau;
@@ -1444,7 +1456,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             for (int m = 6; m >= 0; --m) {
                 if (m < napplied) {
                     const T* cb = sB + m * 24;
-                    const T g = T(1) / (cb[sel[m]] + prm.r[m]);
+                    const T g = fast_rcp(cb[sel[m]] + prm.r[m]);
                     const T kk = cb[row] * g;
 #pragma unroll
                     for (int j = 0; j < 24; ++j) p[j] += kk * cb[j];
@@ -1541,18 +1553,16 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     group_sync();
     if (valid) {
         T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
-        int lg2 = lig;                      // (recomputed, not carried through the round in registers)
-        asm volatile("" : "+v"(lg2));
+        int off[2 * NV];
+#pragma unroll
+        for (int k = 0; k < 2 * NV; ++k) off[k] = sOff[lig * OS + k];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int e2 = lg2 + k * LPI;
+            const int e2 = lig + k * LPI;
             if (e2 < 150) {
-                int i, j;
                 T2 v;
-                unpack_ij(2 * e2, i, j);
-                v.x = sB[i * PS + j];
-                unpack_ij(2 * e2 + 1, i, j);
-                v.y = sB[i * PS + j];
+                v.x = sB[off[2 * k]];
+                v.y = sB[off[2 * k + 1]];
                 gP2[e2] = v;
             }
         }
