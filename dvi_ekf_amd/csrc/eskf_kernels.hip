@@ -475,13 +475,17 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
             const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
-            for (int r = 0; r < nrec; ++r) {
-                if (lane < npiece) {
-                    using T2 = typename Vec2<T>::type;
+            if (lane < npiece) {
+                using T2 = typename Vec2<T>::type;
+                const bool has_y = 2 * lane + 1 < JS;
+                const T* src = sJ + 2 * lane;
+                T2* dst = reinterpret_cast<T2*>(gJ) + lane;
+#pragma unroll 8
+                for (int r = 0; r < nrec; ++r) {    // (unrolled: the LDS reads of eight records are in flight together)
                     T2 v;
-                    v.x = sJ[r * JS + 2 * lane];
-                    v.y = (2 * lane + 1 < JS) ? sJ[r * JS + 2 * lane + 1] : T(0);
-                    reinterpret_cast<T2*>(gJ + (int64_t)r * JW)[lane] = v;
+                    v.x = src[r * JS];
+                    v.y = has_y ? src[r * JS + 1] : T(0);
+                    dst[(int64_t)r * (JW / 2)] = v;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
