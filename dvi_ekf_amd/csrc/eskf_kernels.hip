@@ -7,10 +7,11 @@
 // (SURVEY.md App. A/B).
 //
 // One predict(+update) step = eskf_pre_kernel (lane per instance: nominal state, Jacobian blocks,
-// residual) -> eskf_cov_kernel (LPI lanes per instance: covariance propagation, gain, covariance
-// update) ; the error injection of an update is applied by the next step's pre kernel or, when the
-// state is read in between, by eskf_post_kernel.  See the "Work split" comment below and
-// DESIGN.md section 4.
+// residual) -> eskf_cov_rows_kernel (32 lanes per instance, rows of P in registers: covariance
+// propagation, the measurements one after the other, reset; eskf_cov_kernel<LPI> is the same step
+// on an LDS image of P and also forms the gain matrix) ; the error injection of an update is applied
+// by the next step's pre kernel or, when the state is read in between, by eskf_post_kernel.  See
+// the "Work split" comment below and DESIGN.md section 4.
 //
 // HBM layout:
 //   P  [B][300]  symmetric-packed, one contiguous 2.4 KB record per instance: 12 "double rows" r
@@ -381,7 +382,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
 // lane-per-instance kernels (64 instances per wave, every lane useful):
 //
 //   eskf_pre_kernel   x, IMU samples, measurement -> predicted x, Jacobian blocks J[n], residual
-//   eskf_cov_kernel   P, J[n], residual           -> P, error state e, status      (LPI lanes / instance)
+//   eskf_cov_*_kernel P, J[n], residual           -> P, error state e, status      (32 lanes / instance)
 //   eskf_post_kernel  predicted x, e, status      -> x                              (injection)
 //
 // The nominal state never reads P, so one pre-launch covers all n_pred predicts of an epoch
