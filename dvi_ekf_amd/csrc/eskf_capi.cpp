@@ -302,6 +302,26 @@ int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes) {
     return DVI_ESKF_OK;
 }
 
+int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int64_t n, const void* R_WC,
+                            const void* om_CW, const void* acc_CW, const void* alp_CW, const void* notch,
+                            int notch_per_sample, const double* dofs6, const void* p_CW, const void* v_CW, void* om_B,
+                            void* acc_B, void* p_BW, void* R_WB, void* v_BW, void* stream) {
+    if (!p || n < 0 || !dofs6) return DVI_ESKF_EINVAL;
+    if (dtype != DVI_ESKF_F64 && dtype != DVI_ESKF_F32) return DVI_ESKF_EINVAL;
+    if (n == 0) return DVI_ESKF_OK;
+    if (!R_WC || !om_CW || !acc_CW || !alp_CW || !notch || !om_B || !acc_B) return DVI_ESKF_EINVAL;
+    if ((p_BW && !p_CW) || (v_BW && !v_CW)) return DVI_ESKF_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DVI_ESKF_ENODEV;
+    DeviceGuard g(device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    eskf::HostParams hp{};
+    hp.L = p->L; hp.theta_cam = p->theta_cam;
+    hipError_t e = eskf::launch_imu(dtype, n, R_WC, om_CW, acc_CW, alp_CW, notch, notch_per_sample ? 1 : 0, p_CW, v_CW,
+                                    om_B, acc_B, p_BW, R_WB, v_BW, dofs6, hp, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
 const char* dvi_eskf_strerror(int code) {
     switch (code) {
         case DVI_ESKF_OK: return "ok";

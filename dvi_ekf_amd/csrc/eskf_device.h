@@ -79,4 +79,8 @@ hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, 
 hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,
                          void* acc3, void* qo4, void* dofs6, hipStream_t stream);
 
+hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, const void* acc, const void* alp,
+                      const void* notch, int notch_stride, const void* p_CW, const void* v_CW, void* om_B, void* acc_B,
+                      void* p_BW, void* R_WB, void* v_BW, const double* dofs6, const HostParams& hp, hipStream_t stream);
+
 }  // namespace eskf

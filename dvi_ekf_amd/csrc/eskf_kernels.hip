@@ -1310,7 +1310,6 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         }
     }
 
-    const int jwords = prm.q_gyro ? J_FULL : J_CORE;
     constexpr int NJ = (J_FULL + LPI - 1) / LPI;
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
@@ -1635,6 +1634,97 @@ __global__ void unpack_state_kernel(int64_t B, const T* xs, const T* Ppk, T* x26
 }
 
 // ----------------------------------------------------------------------------------
+// input synthesis: noise-free IMU sample from the camera trajectory through the probe
+// kinematics -- f_imu_meas / f_imu of kinematics/equations.py:8-41,54-69 as driven by
+// Imu.eval_expr_single (models/Imu.py:141-196) and Imu.ref_vals (305-315).  Lane per sample.
+// Only the notch joint moves (Probe.py:382-410), so relative velocity and acceleration of C in B
+// vanish and om_CB = z6 q7', alp_CB = z6 q7''.
+// ----------------------------------------------------------------------------------
+struct ImuArgs {
+    int64_t n;
+    const void* R_WC;    // [n][9] row-major
+    const void* om_CW;   // [n][3] camera angular rate in W
+    const void* acc_CW;  // [n][3] camera acceleration in W
+    const void* alp_CW;  // [n][3] camera angular acceleration in W
+    const void* notch;   // [n][3] (q7, q7', q7'') or [3]
+    int notch_stride;    // 1: per sample, 0: broadcast
+    const void* p_CW;    // nullable [n][3]  (reference pose only)
+    const void* v_CW;    // nullable [n][3]
+    void* om_B;          // [n][3]
+    void* acc_B;         // [n][3]
+    void* p_BW;          // nullable [n][3]
+    void* R_WB;          // nullable [n][9]
+    void* v_BW;          // nullable [n][3]
+    double dofs[6];      // ground-truth joint values q1..q6
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_imu_kernel(ImuArgs a, DevParams<T> prm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const T* gn = reinterpret_cast<const T*>(a.notch) + (a.notch_stride ? i * 3 : 0);
+    const T q7 = gn[0], q7d = gn[1], q7dd = gn[2];
+    T dofs[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dofs[k] = (T)a.dofs[k];
+    const ProbeTrig<T> t = probe_trig(dofs, q7);
+    T pB[3], RBC[9], z6[3];
+    probe_pose(t, dofs, prm.L, prm.st, prm.ct, pB, RBC, z6);
+    T Rc[9], om_c[3], acc_c[3], alp_c[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rc[k] = reinterpret_cast<const T*>(a.R_WC)[i * 9 + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        om_c[k] = reinterpret_cast<const T*>(a.om_CW)[i * 3 + k];
+        acc_c[k] = reinterpret_cast<const T*>(a.acc_CW)[i * 3 + k];
+        alp_c[k] = reinterpret_cast<const T*>(a.alp_CW)[i * 3 + k];
+    }
+    // R_WB = R_WC R_BC^T   (equations.py:9)
+    T R[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R[3 * r + c] = Rc[3 * r] * RBC[3 * c] + Rc[3 * r + 1] * RBC[3 * c + 1] + Rc[3 * r + 2] * RBC[3 * c + 2];
+    T omCB[3], alpCB[3], Rom[3], Ralp[3], lever[3], W_om[3], W_alp[3], W_acc[3], cr[3], cr2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { omCB[k] = z6[k] * q7d; alpCB[k] = z6[k] * q7dd; }
+    mat3_vec(R, omCB, Rom);
+    mat3_vec(R, alpCB, Ralp);
+    mat3_vec(R, pB, lever);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W_om[k] = om_c[k] - Rom[k];                  // equations.py:10
+    cross3(W_om, Rom, cr);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W_alp[k] = alp_c[k] - Ralp[k] - cr[k];       // equations.py:24-27
+    T om_x_lever[3];
+    cross3(W_om, lever, om_x_lever);
+    cross3(W_alp, lever, cr);
+    cross3(W_om, om_x_lever, cr2);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) W_acc[k] = acc_c[k] - cr[k] - cr2[k];        // equations.py:29-37 (v_CB = acc_CB = 0)
+    T oB[3], aB[3];
+    mat3T_vec(R, W_om, oB);
+    mat3T_vec(R, W_acc, aB);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        reinterpret_cast<T*>(a.om_B)[i * 3 + k] = oB[k];
+        reinterpret_cast<T*>(a.acc_B)[i * 3 + k] = aB[k];
+    }
+    if (a.R_WB) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) reinterpret_cast<T*>(a.R_WB)[i * 9 + k] = R[k];
+    }
+    if (a.p_BW && a.p_CW) {                                                  // equations.py:11
+#pragma unroll
+        for (int k = 0; k < 3; ++k) reinterpret_cast<T*>(a.p_BW)[i * 3 + k] = reinterpret_cast<const T*>(a.p_CW)[i * 3 + k] - lever[k];
+    }
+    if (a.v_BW && a.v_CW) {                                                  // equations.py:12-13
+#pragma unroll
+        for (int k = 0; k < 3; ++k) reinterpret_cast<T*>(a.v_BW)[i * 3 + k] = reinterpret_cast<const T*>(a.v_CW)[i * 3 + k] - om_x_lever[k];
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // host-side launchers
 // ----------------------------------------------------------------------------------
 template <typename T, int LPI>
@@ -1740,6 +1830,22 @@ hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, 
         hipLaunchKernelGGL(unpack_state_kernel<float>, dim3(blocks), dim3(threads), 0, stream, B, (const float*)xs,
                            (const float*)Ppk, (float*)x26, (float*)P576, (float*)om3, (float*)acc3, (float*)qo4,
                            (float*)dofs6);
+    return hipGetLastError();
+}
+
+hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, const void* acc, const void* alp,
+                      const void* notch, int notch_stride, const void* p_CW, const void* v_CW, void* om_B, void* acc_B,
+                      void* p_BW, void* R_WB, void* v_BW, const double* dofs6, const HostParams& hp, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    ImuArgs a;
+    a.n = n; a.R_WC = R_WC; a.om_CW = om; a.acc_CW = acc; a.alp_CW = alp; a.notch = notch; a.notch_stride = notch_stride;
+    a.p_CW = p_CW; a.v_CW = v_CW; a.om_B = om_B; a.acc_B = acc_B; a.p_BW = p_BW; a.R_WB = R_WB; a.v_BW = v_BW;
+    for (int k = 0; k < 6; ++k) a.dofs[k] = dofs6[k];
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(eskf_imu_kernel<double>, dim3(blocks), dim3(256), 0, stream, a, make_dev_params<double>(hp));
+    else
+        hipLaunchKernelGGL(eskf_imu_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, make_dev_params<float>(hp));
     return hipGetLastError();
 }
 

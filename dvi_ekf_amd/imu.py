@@ -43,6 +43,56 @@ def imu_measurement(R_WC, W_om_CW, W_acc_CW, W_alp_CW, fwkin):
     return R_WB.T @ W_om, R_WB.T @ W_acc
 
 
+def synthesize_on_device(R_WC, om_CW, acc_CW, alp_CW, notch, dofs6, length, theta_cam, p_CW=None, v_CW=None,
+                         dtype=None, device=None):
+    """The whole IMU stream of a run in one launch of the HIP library (``dvi_eskf_imu_synthesize``,
+    SURVEY 8(f1)): what ``Imu.eval_expr_single`` (Imu.py:141-196) evaluates per sample on the host.
+
+    R_WC [n,3,3], om_CW/acc_CW/alp_CW [n,3], notch [n,3] or [3] = (q7, q7', q7''), dofs6 = the six
+    ground-truth joint values.  Returns device tensors ``om_B, acc_B`` [n,3] and, when ``p_CW`` and
+    ``v_CW`` are given, also the reference pose ``p_BW [n,3], R_WB [n,3,3], v_BW [n,3]``
+    (``Imu.ref_vals``, Imu.py:305-315).  No CPU fallback: raises if the library is missing."""
+    import ctypes as C
+
+    import torch
+
+    from . import _capi
+    lib = _capi.lib()
+    dtype = dtype or torch.float64
+    device = torch.device(device if device is not None else "cuda:0")
+
+    def dev(a, shape):
+        t = torch.as_tensor(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(device=device, dtype=dtype)
+        return t.reshape(shape).contiguous()
+
+    n = int(np.asarray(om_CW).reshape(-1, 3).shape[0])
+    tR, tom, tacc, talp = dev(R_WC, (n, 9)), dev(om_CW, (n, 3)), dev(acc_CW, (n, 3)), dev(alp_CW, (n, 3))
+    notch = np.asarray(notch, dtype=np.float64)
+    per_sample = notch.ndim == 2
+    tn = dev(notch, (n, 3) if per_sample else (3,))
+    want_ref = p_CW is not None and v_CW is not None
+    tp = dev(p_CW, (n, 3)) if want_ref else None
+    tv = dev(v_CW, (n, 3)) if want_ref else None
+    out_om = torch.empty((n, 3), dtype=dtype, device=device)
+    out_acc = torch.empty((n, 3), dtype=dtype, device=device)
+    out_p = torch.empty((n, 3), dtype=dtype, device=device) if want_ref else None
+    out_R = torch.empty((n, 9), dtype=dtype, device=device) if want_ref else None
+    out_v = torch.empty((n, 3), dtype=dtype, device=device) if want_ref else None
+    prm = _capi.Params()
+    prm.L, prm.theta_cam = float(length), float(theta_cam)
+    d6 = (C.c_double * 6)(*[float(v) for v in dofs6])
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    with torch.cuda.device(device):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _capi.check(lib.dvi_eskf_imu_synthesize(C.byref(prm), 0 if dtype == torch.float64 else 1, device.index or 0, n,
+                                                ptr(tR), ptr(tom), ptr(tacc), ptr(talp), ptr(tn), int(per_sample), d6,
+                                                ptr(tp), ptr(tv), ptr(out_om), ptr(out_acc), ptr(out_p), ptr(out_R),
+                                                ptr(out_v), stream), "dvi_eskf_imu_synthesize")
+    if want_ref:
+        return out_om, out_acc, out_p, out_R.reshape(n, 3, 3), out_v
+    return out_om, out_acc
+
+
 class ImuRefTraj:
     """Desired IMU trajectory log, 14 columns (trajectory/ImuRefTraj.py:18-55)."""
 

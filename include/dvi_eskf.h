@@ -135,6 +135,21 @@ int dvi_eskf_flush(dvi_eskf* h, void* stream);
 void* dvi_eskf_raw_P(dvi_eskf* h);
 void* dvi_eskf_raw_x(dvi_eskf* h);
 
+/* Input synthesis, the step in front of the path: noise-free IMU samples from the
+ * camera trajectory through the probe kinematics -- f_imu_meas / f_imu of
+ * kinematics/equations.py:8-41,54-69 as driven by Imu.eval_expr_single (models/Imu.py:141-196)
+ * and Imu.ref_vals (Imu.py:305-315).  Stateless; one sample per lane.  Device pointers:
+ *   R_WC [n,9] row-major camera attitude, om_CW / acc_CW / alp_CW [n,3] camera angular rate,
+ *   acceleration and angular acceleration in W, notch [n,3] = (q7, q7', q7'') per sample or [3];
+ *   dofs6: HOST array, the ground-truth joint values q1..q6 (Probe.py:382-410).
+ * Outputs: om_B, acc_B [n,3] (body-frame rate and acceleration; no gravity, bias or noise), and --
+ * when not NULL -- the reference pose p_BW [n,3] (needs p_CW), R_WB [n,9], v_BW [n,3] (needs v_CW).
+ * Only L and theta_cam of the parameter block are used. */
+int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int64_t n, const void* R_WC,
+                            const void* om_CW, const void* acc_CW, const void* alp_CW, const void* notch,
+                            int notch_per_sample, const double* dofs6, const void* p_CW, const void* v_CW,
+                            void* om_B, void* acc_B, void* p_BW, void* R_WB, void* v_BW, void* stream);
+
 /* Covariance kernel selector (for experiments and cross-checks).
  * DVI_ESKF_LANES_ROWS (default): row-resident kernel -- lane i of an instance keeps row i of P in
  * registers, 32 lanes per instance, two instances per wavefront.

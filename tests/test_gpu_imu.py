@@ -1,0 +1,77 @@
+"""IMU synthesis on the device (dvi_eskf_imu_synthesize) against the host restatement
+of f_imu_meas / f_imu (dvi_ekf_amd.imu, pinned by tests/test_oracle_golden.py to the reference's saved
+IMU reference trajectory)."""
+import numpy as np
+import pytest
+import torch
+
+from dvi_ekf_amd.camera import create_camera
+from dvi_ekf_amd.imu import Imu, imu_measurement, imu_pose_from_camera, synthesize_on_device
+from dvi_ekf_amd.probe import SimpleProbe, probe_fwkin
+from tests.helpers import default_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _samples(n_notch_mode):
+    cfg, *_ = default_run(golden_compat=False, fast=False)
+    cam = create_camera(cfg).interpolate(10)
+    n = len(cam.t)
+    R = np.array(cam.R)
+    rng = np.random.default_rng(7)
+    if n_notch_mode == "per-sample":
+        notch = np.stack([0.3 * np.sin(np.linspace(0, 3, n)), 0.2 * np.cos(np.linspace(0, 3, n)), rng.normal(0, 0.05, n)], 1)
+    else:
+        notch = np.array([0.0, 0.0, 0.0])
+    return cfg, cam, n, R, notch
+
+
+@pytest.mark.parametrize("mode", ["broadcast", "per-sample"])
+def test_device_imu_stream_matches_host(mode):
+    cfg, cam, n, R, notch = _samples(mode)
+    probe = SimpleProbe(cfg.model.length, cfg.model.angle)
+    dofs = probe.q[:6]
+    om_d, acc_d, p_d, R_d, v_d = synthesize_on_device(R, cam.om.T, cam.acc.T, cam.alp.T, notch, dofs, probe.scope_length,
+                                                      probe.theta_cam, p_CW=cam.p.T, v_CW=cam.v.T)
+    om_h, acc_h, p_h, R_h, v_h = [], [], [], [], []
+    for i in range(n):
+        nt = notch[i] if notch.ndim == 2 else notch
+        fk = probe_fwkin(dofs, nt, probe.scope_length, probe.theta_cam)
+        o, a = imu_measurement(R[i], cam.om[:, i], cam.acc[:, i], cam.alp[:, i], fk)
+        pr, Rr, vr = imu_pose_from_camera([cam.p[:, i], R[i], cam.v[:, i], cam.om[:, i], cam.acc[:, i], cam.alp[:, i]], fk)
+        om_h.append(o); acc_h.append(a); p_h.append(pr); R_h.append(Rr); v_h.append(vr)
+    for name, d, h in (("om", om_d, om_h), ("acc", acc_d, acc_h), ("p_ref", p_d, p_h), ("R_ref", R_d, R_h), ("v_ref", v_d, v_h)):
+        d = d.cpu().numpy()
+        h = np.array(h)
+        err = np.abs(d - h).max() / max(1.0, np.abs(h).max())
+        assert err <= 1e-13, (name, err)       # fp64: same formulas, different association only
+
+
+def test_device_imu_matches_reference_shaped_imu_object():
+    """The values Filter.run consumes: Imu.eval_expr_single over the interpolated camera."""
+    cfg, cam, n, R, _ = _samples("broadcast")
+    probe = SimpleProbe(cfg.model.length, cfg.model.angle)
+    imu = Imu(probe, cam)
+    q, qd, qdd = probe.joint_dofs
+    host = np.array([np.concatenate(imu.eval_expr_single(cam.t[i], q, qd, qdd, cam.acc[:, i], R[i], cam.om[:, i], cam.alp[:, i]))
+                     for i in range(n)])
+    om_d, acc_d = synthesize_on_device(R, cam.om.T, cam.acc.T, cam.alp.T, [q[6], qd[6], qdd[6]], q[:6], probe.scope_length,
+                                       probe.theta_cam)
+    dev = torch.cat([om_d, acc_d], 1).cpu().numpy()
+    assert np.abs(dev - host).max() <= 1e-13 * max(1.0, np.abs(host).max())
+
+
+def test_device_imu_fp32_and_argument_checks():
+    cfg, cam, n, R, notch = _samples("broadcast")
+    probe = SimpleProbe(cfg.model.length, cfg.model.angle)
+    om64, acc64 = synthesize_on_device(R, cam.om.T, cam.acc.T, cam.alp.T, notch, probe.q[:6], probe.scope_length, probe.theta_cam)
+    om32, acc32 = synthesize_on_device(R, cam.om.T, cam.acc.T, cam.alp.T, notch, probe.q[:6], probe.scope_length, probe.theta_cam,
+                                       dtype=torch.float32)
+    assert float((om32.double() - om64).abs().max()) <= 1e-5 * max(1.0, float(om64.abs().max()))
+    assert float((acc32.double() - acc64).abs().max()) <= 1e-4 * max(1.0, float(acc64.abs().max()))
+    from dvi_ekf_amd import _capi
+    import ctypes as C
+    L = _capi.lib()
+    prm = _capi.Params()
+    assert L.dvi_eskf_imu_synthesize(C.byref(prm), 0, 0, 4, None, None, None, None, None, 0, (C.c_double * 6)(), None, None,
+                                     None, None, None, None, None, None) == -1     # DVI_ESKF_EINVAL, nothing launched
