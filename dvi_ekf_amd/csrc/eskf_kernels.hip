@@ -423,6 +423,25 @@ __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const S
     for (int i = 0; i < 6; ++i) xs[(10 + i) * B + b] = s.dofs[i];
 }
 
+// IMU sample `ip` of instance b; zeros beyond the last one (assigned on every path, so that the
+// registers of the sample before are free as soon as it has been used)
+template <typename T>
+__device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64_t b, T& dt, T (&om)[3], T (&acc)[3]) {
+    if (ip < a.n_pred) {
+        const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
+        dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? (int64_t)ip * a.B + b : ip];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            om[i] = reinterpret_cast<const T*>(a.om)[so + i];
+            acc[i] = reinterpret_cast<const T*>(a.acc)[so + i];
+        }
+    } else {
+        dt = T(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { om[i] = T(0); acc[i] = T(0); }
+    }
+}
+
 // ---- lane-per-instance: nominal propagation + residual (blockIdx.y = 0) and Jacobian blocks
 // (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
@@ -448,11 +467,29 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
-    const bool inject_now = a.apply_pending && !(a.status_ws[b] & DVI_STATUS_SINGULAR);
+    // the pending error state is fetched together with its status word and the state (one round
+    // trip to HBM, not two), whether or not the status lets it be applied
     T epend[24];
-    if (inject_now) {
+    int pend_status = 0;
+    if (a.apply_pending) {
+        pend_status = a.status_ws[b];
 #pragma unroll
         for (int i = 0; i < 24; ++i) epend[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i];
+    }
+    const bool inject_now = a.apply_pending && !(pend_status & DVI_STATUS_SINGULAR);
+    // ... and so is the first IMU sample (the following ones are fetched at the end of the predict before)
+    T dt0, om0[3], acc0[3];
+    load_imu_sample(a, 0, b, dt0, om0, acc0);
+    // wave 0 also fetches the measurement now and parks it in LDS until the residual is formed
+    // (same round trip; kept in registers it would cost eight values through the whole propagation)
+    T* sM = sJ + 64 * JS + lane * 9;
+    if (!jac_role && a.do_update) {
+        const int64_t mo = a.meas_stride ? b : 0;
+        const T* gpos = reinterpret_cast<const T*>(a.pos) + mo * 3;
+        const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
+        T m[8] = {gpos[0], gpos[1], gpos[2], gq[0], gq[1], gq[2], gq[3], reinterpret_cast<const T*>(a.notch)[mo]};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sM[i] = m[i];
     }
     __syncthreads();                               // every read of the old state (and of the pending
                                                    // error state) precedes this step's writes
@@ -460,13 +497,8 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     if (jac_role) {
         // ---- wave 1: Jacobian blocks of every predict of this launch ---------------------------
         const int npiece = prm.q_gyro ? 43 : 34;   // 16-byte pieces of a record: 85 / 67 words
+        T dt = dt0, om_n[3] = {om0[0], om0[1], om0[2]}, acc_n[3] = {acc0[0], acc0[1], acc0[2]};
         for (int ip = 0; ip < a.n_pred; ++ip) {
-            const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
-            const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
-            const T* gom = reinterpret_cast<const T*>(a.om) + so;
-            const T* gac = reinterpret_cast<const T*>(a.acc) + so;
-            const T dt = gdt[0];
-            T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
             // the blocks are written straight into this lane's staging row (the struct IS the record),
             // so they do not occupy registers; only this wavefront touches sJ: wave-level ordering
             Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
@@ -492,28 +524,23 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
         }
         return;
     }
     // ---- wave 0: nominal state through every predict, then the residual -------------------------
+    T dt = dt0, om_n[3] = {om0[0], om0[1], om0[2]}, acc_n[3] = {acc0[0], acc0[1], acc0[2]};
     for (int ip = 0; ip < a.n_pred; ++ip) {
-        const T* gdt = reinterpret_cast<const T*>(a.dt) + (a.dt_stride ? (int64_t)ip * a.B + b : ip);
-        const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
-        const T* gom = reinterpret_cast<const T*>(a.om) + so;
-        const T* gac = reinterpret_cast<const T*>(a.acc) + so;
-        const T dt = gdt[0];
-        T om_n[3] = {gom[0], gom[1], gom[2]}, acc_n[3] = {gac[0], gac[1], gac[2]};
         Jac<T> J;
         predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
+        load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
     }
     if (!live) return;
     if (a.do_update) {
         // measurement correction and residual (Filter.py:364-375)
-        const int64_t mo = a.meas_stride ? b : 0;
-        const T* gpos = reinterpret_cast<const T*>(a.pos) + mo * 3;
-        const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
-        const T ang_notch = reinterpret_cast<const T*>(a.notch)[mo];
-        T qraw[4] = {gq[0], gq[1], gq[2], gq[3]};
+        const T gpos[3] = {sM[0], sM[1], sM[2]};
+        const T ang_notch = sM[7];
+        T qraw[4] = {sM[3], sM[4], sM[5], sM[6]};
         T nq[4] = {T(0), T(0), T(0), T(1)};
         t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
         T qm[4], qe[4];
@@ -1762,7 +1789,7 @@ template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    const size_t stage_bytes = (size_t)64 * (prm.q_gyro ? J_FULL : J_CORE) * sizeof(T);
+    const size_t stage_bytes = (size_t)64 * ((prm.q_gyro ? J_FULL : J_CORE) + 9) * sizeof(T);   // + parked measurement
     hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
