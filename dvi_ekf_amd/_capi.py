@@ -48,6 +48,7 @@ SIGNATURES = {
     "dvi_eskf_raw_P": (_vp, [_vp]),
     "dvi_eskf_raw_x": (_vp, [_vp]),
     "dvi_eskf_set_lanes_per_instance": (_i, [_vp, _i]),
+    "dvi_eskf_log_rows": (_i, [_vp, C.c_double, _vp, _vp]),
     "dvi_eskf_imu_synthesize": (_i, [C.POINTER(Params), _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _dp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
     "dvi_eskf_strerror": (C.c_char_p, [_i]),

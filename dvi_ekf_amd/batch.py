@@ -92,6 +92,13 @@ class BatchedESKF:
             return t.reshape((1, *tail)), 0
         raise ValueError(f"expected shape {(self.batch, *tail)} or {tail}, got {tuple(t.shape)}")
 
+    def log_rows(self, t: float) -> torch.Tensor:
+        """The 30-column trajectory-log row of every instance (FilterTraj.py:12-41), formed on the
+        device: [B,30]."""
+        rows = torch.empty((self.batch, 30), dtype=self.dtype, device=self.device)
+        _capi.check(self.lib.dvi_eskf_log_rows(self._h, float(t), _ptr(rows), self._stream()), "dvi_eskf_log_rows")
+        return rows
+
     def set_lanes_per_instance(self, lanes: int) -> None:
         _capi.check(self.lib.dvi_eskf_set_lanes_per_instance(self._h, int(lanes)), "set_lanes_per_instance")
 

@@ -302,6 +302,15 @@ int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes) {
     return DVI_ESKF_OK;
 }
 
+int dvi_eskf_log_rows(dvi_eskf* h, double t, void* rows_out, void* stream) {
+    if (!h || !rows_out) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(h, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_log_rows(h->dtype, h->B, h->d_x, t, rows_out, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
 int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int64_t n, const void* R_WC,
                             const void* om_CW, const void* acc_CW, const void* alp_CW, const void* notch,
                             int notch_per_sample, const double* dofs6, const void* p_CW, const void* v_CW, void* om_B,

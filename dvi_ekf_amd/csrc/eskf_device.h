@@ -83,4 +83,6 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
                       const void* notch, int notch_stride, const void* p_CW, const void* v_CW, void* om_B, void* acc_B,
                       void* p_BW, void* R_WB, void* v_BW, const double* dofs6, const HostParams& hp, hipStream_t stream);
 
+hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream);
+
 }  // namespace eskf

@@ -1752,6 +1752,50 @@ __global__ __launch_bounds__(256) void eskf_imu_kernel(ImuArgs a, DevParams<T> p
 }
 
 // ----------------------------------------------------------------------------------
+// trajectory log: the 30-column row of trajectory/FilterTraj.py:12-41 per instance,
+// straight from the state record: t | p v euler_xyz_deg(q) q_wxyz | deg(dofs[0:3]) dofs[3:6] |
+// p_cam euler_xyz_deg(q_cam) q_cam_wxyz.  Euler angles as scipy's as_euler('xyz') (extrinsic).
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ double t_atan2(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float t_atan2(float y, float x) { return atan2f(y, x); }
+
+template <typename T>
+__device__ __forceinline__ void euler_xyz_deg(const T* q, T* e) {
+    T M[9];
+    quat_to_mat(q, M);
+    const T k = T(57.29577951308232087679815481410517);
+    T sb = M[6];
+    sb = sb > T(1) ? T(1) : (sb < T(-1) ? T(-1) : sb);
+    e[0] = k * t_atan2(M[7], M[8]);
+    e[1] = -k * t_asin(sb);
+    e[2] = k * t_atan2(M[3], M[0]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_log_rows_kernel(int64_t B, const T* xs, T tstamp, T* rows) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    State<T> s;
+    load_state(xs, B, b, s);
+    T* r = rows + b * 30;
+    const T k = T(57.29577951308232087679815481410517);
+    T e[3];
+    r[0] = tstamp;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { r[1 + i] = s.p[i]; r[4 + i] = s.v[i]; r[20 + i] = s.pc[i]; }
+    euler_xyz_deg(s.q, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[7 + i] = e[i];
+    r[10] = s.q[3]; r[11] = s.q[0]; r[12] = s.q[1]; r[13] = s.q[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { r[14 + i] = k * s.dofs[i]; r[17 + i] = s.dofs[3 + i]; }
+    euler_xyz_deg(s.qc, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r[23 + i] = e[i];
+    r[26] = s.qc[3]; r[27] = s.qc[0]; r[28] = s.qc[1]; r[29] = s.qc[2];
+}
+
+// ----------------------------------------------------------------------------------
 // host-side launchers
 // ----------------------------------------------------------------------------------
 template <typename T, int LPI>
@@ -1873,6 +1917,16 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
         hipLaunchKernelGGL(eskf_imu_kernel<double>, dim3(blocks), dim3(256), 0, stream, a, make_dev_params<double>(hp));
     else
         hipLaunchKernelGGL(eskf_imu_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, make_dev_params<float>(hp));
+    return hipGetLastError();
+}
+
+hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((B + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(eskf_log_rows_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, (const double*)xs, t, (double*)rows);
+    else
+        hipLaunchKernelGGL(eskf_log_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)xs, (float)t, (float*)rows);
     return hipGetLastError();
 }
 

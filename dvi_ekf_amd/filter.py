@@ -65,7 +65,7 @@ class Filter:
         self.Fi = None
 
         self.traj = FilterTraj("kf")
-        self.traj.append_propagated_states(self._config.min_t, self._states)
+        self.traj.append_row(self._log_row(self._config.min_t))
         self.mse = 0
         self.update_mse = 0
         self.status = np.zeros(self.batch, dtype=np.int32)
@@ -74,6 +74,10 @@ class Filter:
     @property
     def device_filter(self) -> BatchedESKF:
         return self._dev
+
+    def _log_row(self, t: float) -> np.ndarray:
+        """The 30-column FilterTraj row of instance 0 (FilterTraj.py:12-41), formed on the device."""
+        return self._dev.log_rows(t)[0].cpu().numpy()
 
     @property
     def _states(self) -> State:
@@ -143,7 +147,7 @@ class Filter:
         self._dev.set_state(x=x0.vector, P=np.asarray(cov0, dtype=float), om_old=self.imu.om.squeeze(),
                             acc_old=self.imu.acc.squeeze())
         self.traj.reset()
-        self.traj.append_propagated_states(self._config.min_t, self._states)
+        self.traj.append_row(self._log_row(self._config.min_t))
         self.mse = 0
 
     def update_noise_matrices(self) -> None:
@@ -197,7 +201,7 @@ class Filter:
     def propagate(self, t, om, acc) -> None:
         """Filter.propagate (Filter.py:219-230) -- one kernel launch."""
         self._dev.predict(self._dt, np.asarray(om, dtype=float), np.asarray(acc, dtype=float))
-        self.traj.append_propagated_states(t, self._states)
+        self.traj.append_row(self._log_row(t))
 
     def update(self, t: float, camera, ang_notch: float):
         """Filter.update (Filter.py:351-395).  Returns K (24x7, instance 0) or ``None`` when
@@ -210,7 +214,7 @@ class Filter:
             print("ERROR: Singular matrix!")
             print("Stopping simulation.")
             return None
-        self.traj.append_updated_states(t, self._states)
+        self.traj.overwrite_last_row(self._log_row(t))    # FilterTraj.py:66-69
         return K[0].cpu().numpy()
 
     # -- metrics (host side, Filter.py:397-455) -------------------------------------------------

@@ -42,6 +42,18 @@ class FilterTraj:
             else:
                 getattr(self, lab).append(data[i])
 
+    def append_row(self, data) -> None:
+        """A ready-made 30-column row (formed on the device, BatchedESKF.log_rows)."""
+        for i, lab in enumerate(self.labels):
+            if getattr(self, lab) is None:
+                setattr(self, lab, [float(data[i])])
+            else:
+                getattr(self, lab).append(float(data[i]))
+
+    def overwrite_last_row(self, data) -> None:
+        for i, lab in enumerate(self.labels):
+            getattr(self, lab)[-1] = float(data[i])
+
     def append_updated_states(self, t: float, state: State) -> None:
         """The row of an update step overwrites the last propagated row (FilterTraj.py:66-69)."""
         data = euler_measurement_row(t, state)

@@ -135,6 +135,13 @@ int dvi_eskf_flush(dvi_eskf* h, void* stream);
 void* dvi_eskf_raw_P(dvi_eskf* h);
 void* dvi_eskf_raw_x(dvi_eskf* h);
 
+/* Trajectory log, the step behind the path: one 30-column row per instance in the
+ * layout of trajectory/FilterTraj.py:12-41 (what Filter.save()/plot() and the saved golden
+ * trajectory use): t | x y z vx vy vz rx ry rz qw qx qy qz | dof1..3 [deg] dof4..6 |
+ * xc yc zc rx_c ry_c rz_c qwc qxc qyc qzc, Euler angles extrinsic xyz in degrees.
+ * rows_out [B,30] in the handle's dtype; applies a pending injection first. */
+int dvi_eskf_log_rows(dvi_eskf* h, double t, void* rows_out, void* stream);
+
 /* Input synthesis, the step in front of the path: noise-free IMU samples from the
  * camera trajectory through the probe kinematics -- f_imu_meas / f_imu of
  * kinematics/equations.py:8-41,54-69 as driven by Imu.eval_expr_single (models/Imu.py:141-196)

@@ -75,3 +75,22 @@ def test_device_imu_fp32_and_argument_checks():
     prm = _capi.Params()
     assert L.dvi_eskf_imu_synthesize(C.byref(prm), 0, 0, 4, None, None, None, None, None, 0, (C.c_double * 6)(), None, None,
                                      None, None, None, None, None, None) == -1     # DVI_ESKF_EINVAL, nothing launched
+
+
+def test_device_log_rows_match_host_log_format():
+    """the 30-column FilterTraj row formed on the device equals the host-side row
+    (traj.euler_measurement_row over State.from_vector) for every instance, before and after a step."""
+    from dvi_ekf_amd.state import State
+    from dvi_ekf_amd.traj import euler_measurement_row
+    from tests.test_gpu_parity import _make, _perturbed_x0
+    B = 37
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    f = _make(cfg, ri, Q, R, sa, so, B, False, _perturbed_x0(ri, B))
+    for k in range(2):
+        rows = f.log_rows(0.25 * k).cpu().numpy()
+        x = f.get_state()["x"].cpu().numpy()
+        for b in range(B):
+            host = np.array(euler_measurement_row(0.25 * k, State.from_vector(x[b])), dtype=float)
+            scale = np.maximum(1.0, np.abs(host))
+            assert (np.abs(rows[b] - host) / scale).max() <= 1e-12, (k, b)
+        f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])   # leaves an injection pending
