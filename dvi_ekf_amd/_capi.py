@@ -37,6 +37,7 @@ SIGNATURES = {
     "dvi_eskf_batch": (_i64, [_vp]),
     "dvi_eskf_dtype": (_i, [_vp]),
     "dvi_eskf_set_noise": (_i, [_vp, _dp, _dp]),
+    "dvi_eskf_set_noise_per_instance": (_i, [_vp, _dp, _dp, _dp, _vp]),
     "dvi_eskf_set_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dvi_eskf_get_state": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dvi_eskf_predict": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp]),

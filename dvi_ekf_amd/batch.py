@@ -92,6 +92,18 @@ class BatchedESKF:
             return t.reshape((1, *tail)), 0
         raise ValueError(f"expected shape {(self.batch, *tail)} or {tail}, got {tuple(t.shape)}")
 
+    def set_noise_per_instance(self, q_diag, r_diag, sigma_om=None) -> None:
+        """One noise model per instance: q_diag [B,13] = diag(Q), r_diag [B,7] = diag(R), sigma_om [B,3]
+        (optional) = Jacobian evaluation point.  ``set_noise`` returns to a shared model."""
+        q = np.ascontiguousarray(np.asarray(q_diag, dtype=np.float64).reshape(self.batch, 13))
+        r = np.ascontiguousarray(np.asarray(r_diag, dtype=np.float64).reshape(self.batch, 7))
+        so = None if sigma_om is None else np.ascontiguousarray(np.asarray(sigma_om, dtype=np.float64).reshape(self.batch, 3))
+        dp = C.POINTER(C.c_double)
+        _capi.check(self.lib.dvi_eskf_set_noise_per_instance(self._h, q.ctypes.data_as(dp), r.ctypes.data_as(dp),
+                                                             None if so is None else so.ctypes.data_as(dp),
+                                                             self._stream()), "dvi_eskf_set_noise_per_instance")
+        self.Q, self.R = np.diag(q[0]), np.diag(r[0])
+
     def log_rows(self, t: float) -> torch.Tensor:
         """The 30-column trajectory-log row of every instance (FilterTraj.py:12-41), formed on the
         device: [B,30]."""

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <vector>
 #include <cstring>
 #include <new>
 
@@ -24,6 +25,7 @@ struct dvi_eskf {
     void* d_e;          // [B][24]
     int32_t* d_status;  // [B]
     bool pending;       // d_e / d_status hold an update whose injection into d_x is still due
+    void* d_noise;      // nullable [B][NOISE_WORDS]: per-instance diag(Q) | diag(R) | sigma_om
 };
 
 namespace {
@@ -37,6 +39,8 @@ void free_buffers(dvi_eskf* h) {
     if (h->d_res) (void)hipFree(h->d_res);
     if (h->d_e) (void)hipFree(h->d_e);
     if (h->d_status) (void)hipFree(h->d_status);
+    if (h->d_noise) (void)hipFree(h->d_noise);
+    h->d_noise = nullptr;
     h->d_P = h->d_x = h->d_J = h->d_res = h->d_e = nullptr;
     h->d_status = nullptr;
     h->jcap = 0;
@@ -90,7 +94,7 @@ eskf::StepArgs base_args(const dvi_eskf* h) {
     eskf::StepArgs a;
     std::memset(&a, 0, sizeof a);
     a.P = h->d_P; a.xs = h->d_x;
-    a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status;
+    a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status; a.noise = h->d_noise;
     a.B = h->B;
     a.rounds = 1;
     return a;
@@ -147,7 +151,8 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     if (!g.ok) return DVI_ESKF_ENODEV;
     dvi_eskf* h = new (std::nothrow) dvi_eskf();
     if (!h) return DVI_ESKF_ENOMEM;
-    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 1; h->pending = false;
+    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 1; h->pending = false; h->d_noise = nullptr;
+    h->hp.q_gyro_any = 0;
     h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
     h->hp.frozen_mask = 0;
     for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);
@@ -175,13 +180,22 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     dvi_eskf* h = new (std::nothrow) dvi_eskf(*src);
     if (!h) return DVI_ESKF_ENOMEM;
     const size_t es = elem_size(src->dtype);
+    h->d_noise = nullptr;             // (the struct copy aliased the source's buffers)
     if (!alloc_buffers(h)) {
         delete h;
         return DVI_ESKF_ENOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
+    const size_t noise_bytes = (size_t)src->B * eskf::NOISE_WORDS * es;
+    if (src->d_noise && hipMalloc(&h->d_noise, noise_bytes) != hipSuccess) {
+        h->d_noise = nullptr;
+        free_buffers(h);
+        delete h;
+        return DVI_ESKF_ENOMEM;
+    }
     if (hipMemcpyAsync(h->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(h->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        hipMemcpyAsync(h->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        (src->d_noise && hipMemcpyAsync(h->d_noise, src->d_noise, noise_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)) {
         free_buffers(h);
         delete h;
         return DVI_ESKF_EHIP;
@@ -230,6 +244,47 @@ int dvi_eskf_set_noise(dvi_eskf* h, const double* Q, const double* R) {
     }
     if (Q) for (int i = 0; i < 13; ++i) h->hp.qd[i] = Q[i * 13 + i];
     if (R) for (int i = 0; i < 7; ++i) h->hp.r[i] = R[i * 7 + i];
+    if (h->d_noise) {                 // back to one noise model for the whole batch
+        DeviceGuard g(h->device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(h->d_noise);
+        h->d_noise = nullptr;
+        h->hp.q_gyro_any = 0;
+    }
+    return DVI_ESKF_OK;
+}
+
+int dvi_eskf_set_noise_per_instance(dvi_eskf* h, const double* q13, const double* r7, const double* sigma_om3,
+                                    void* stream) {
+    if (!h || !q13 || !r7) return DVI_ESKF_EINVAL;
+    const size_t B = (size_t)h->B;
+    for (size_t i = 0; i < B * 13; ++i) if (!std::isfinite(q13[i])) return DVI_ESKF_EINVAL;
+    for (size_t i = 0; i < B * 7; ++i) if (!std::isfinite(r7[i])) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    const size_t es = elem_size(h->dtype);
+    const int W = eskf::NOISE_WORDS;
+    if (!h->d_noise && hipMalloc(&h->d_noise, B * W * es) != hipSuccess) { h->d_noise = nullptr; return DVI_ESKF_ENOMEM; }
+    std::vector<unsigned char> host(B * W * es);
+    int any = 0;
+    for (size_t b = 0; b < B; ++b) {
+        double rec[eskf::NOISE_WORDS] = {0};
+        for (int k = 0; k < 13; ++k) rec[k] = q13[b * 13 + k];
+        for (int k = 0; k < 7; ++k) rec[13 + k] = r7[b * 7 + k];
+        for (int k = 0; k < 3; ++k) rec[20 + k] = sigma_om3 ? sigma_om3[b * 3 + k] : h->hp.sig_om[k];
+        if (rec[3] != 0.0 || rec[4] != 0.0 || rec[5] != 0.0) any = 1;
+        for (int k = 0; k < W; ++k) {
+            if (h->dtype == DVI_ESKF_F64) reinterpret_cast<double*>(host.data())[b * W + k] = rec[k];
+            else reinterpret_cast<float*>(host.data())[b * W + k] = (float)rec[k];
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(h->d_noise, host.data(), host.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return DVI_ESKF_EHIP;
+    h->hp.q_gyro_any = any;
+    for (int k = 0; k < 13; ++k) h->hp.qd[k] = q13[k];     // instance 0, for dvi_eskf_* calls that report the model
+    for (int k = 0; k < 7; ++k) h->hp.r[k] = r7[k];
     return DVI_ESKF_OK;
 }
 

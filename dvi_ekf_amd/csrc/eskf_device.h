@@ -10,7 +10,8 @@ namespace eskf {
 
 constexpr int DVI_STATUS_SINGULAR = 1;
 constexpr int DVI_STATUS_NONFINITE = 2;
-constexpr int JAC_WORDS = 88;   // words per Jacobian record (eskf_kernels.hip: JW)
+constexpr int JAC_WORDS = 88;
+constexpr int NOISE_WORDS = 24; // per-instance noise record: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad   // words per Jacobian record (eskf_kernels.hip: JW)
 
 // constants of one filter configuration, in the kernel's working precision; passed by value
 // as a kernel argument (lives in SGPRs / the kernarg segment)
@@ -30,6 +31,7 @@ struct HostParams {
     double sig_a[3], sig_om[3];
     double qd[13], r[7];
     int frozen_mask, hold_frozen;
+    int q_gyro_any;     // per-instance noise: some instance has a non-zero gyro block in Q
 };
 
 template <typename T>
@@ -43,7 +45,7 @@ inline DevParams<T> make_dev_params(const HostParams& h) {
     for (int i = 0; i < 7; ++i) d.r[i] = (T)h.r[i];
     d.frozen_mask = h.frozen_mask;
     d.hold_frozen = h.hold_frozen;
-    d.q_gyro = (h.qd[3] != 0.0 || h.qd[4] != 0.0 || h.qd[5] != 0.0) ? 1 : 0;
+    d.q_gyro = (h.qd[3] != 0.0 || h.qd[4] != 0.0 || h.qd[5] != 0.0 || h.q_gyro_any) ? 1 : 0;
     return d;
 }
 
@@ -70,6 +72,7 @@ struct StepArgs {
     int dt_stride, imu_stride, meas_stride;
     int rounds;         // instances per wave slot in the covariance kernel (set by the launcher)
     int apply_pending;  // the workspace holds the error state of the previous update: inject it first
+    const void* noise;  // nullable [B][NOISE_WORDS]: per-instance diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
 };
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);

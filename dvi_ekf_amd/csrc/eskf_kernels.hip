@@ -196,8 +196,8 @@ struct Jac {
 // (attitude q, dofs, notch); JAC = false: the blocks are not formed.  The two halves are
 // independent, so the pre kernel gives them to different waves.
 template <typename T, bool NOMINAL = true, bool JAC = true>
-__device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& prm, T dt, const T* om_n,
-                                               const T* acc_n, Jac<T>& J) {
+__device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& prm, const T* sig_om, T dt,
+                                               const T* om_n, const T* acc_n, Jac<T>& J) {
     T R[9], Ro[9];
     quat_to_mat(s.q, R);
     if (JAC) quat_to_mat(s.qo, Ro);
@@ -307,7 +307,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
         // (Probe.py:458)
         T om_t[3], wv[3], cr[3], u_t[3], u_o[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) om_t[i] = s.om_o[i] - prm.sig_om[i];
+        for (int i = 0; i < 3; ++i) om_t[i] = s.om_o[i] - sig_om[i];
         cross3(om_t, p, cr);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -497,12 +497,19 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     if (jac_role) {
         // ---- wave 1: Jacobian blocks of every predict of this launch ---------------------------
         const int npiece = prm.q_gyro ? 43 : 34;   // 16-byte pieces of a record: 85 / 67 words
+        // Jacobian evaluation point n = sigma (Filter.py:330-333): per instance when the handle carries
+        // per-instance noise
+        T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
+        if (a.noise) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sig_om[i] = reinterpret_cast<const T*>(a.noise)[b * NOISE_WORDS + 20 + i];
+        }
         T dt = dt0, om_n[3] = {om0[0], om0[1], om0[2]}, acc_n[3] = {acc0[0], acc0[1], acc0[2]};
         for (int ip = 0; ip < a.n_pred; ++ip) {
             // the blocks are written straight into this lane's staging row (the struct IS the record),
             // so they do not occupy registers; only this wavefront touches sJ: wave-level ordering
             Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
-            predict_scalar<T, false, true>(s, prm, dt, om_n, acc_n, J);
+            predict_scalar<T, false, true>(s, prm, sig_om, dt, om_n, acc_n, J);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     T dt = dt0, om_n[3] = {om0[0], om0[1], om0[2]}, acc_n[3] = {acc0[0], acc0[1], acc0[2]};
     for (int ip = 0; ip < a.n_pred; ++ip) {
         Jac<T> J;
-        predict_scalar<T, true, false>(s, prm, dt, om_n, acc_n, J);
+        predict_scalar<T, true, false>(s, prm, prm.sig_om, dt, om_n, acc_n, J);
         load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
     }
     if (!live) return;
@@ -625,7 +632,9 @@ __device__ __forceinline__ void unpack_ij(int e, int& i, int& j) {
     if (c <= r) { i = r; j = c; } else { i = 23 - r; j = c - r - 1; }
 }
 
-template <typename T, int LPI>
+// PIN: per-instance noise -- diag(Q), diag(R) are read from the instance's noise record instead of the
+// parameter block (a population of differently tuned filters in one batch)
+template <typename T, int LPI, bool PIN = false>
 __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> prm) {
     constexpr int G = 64 / LPI;
     constexpr int REGION = region_words(LPI);
@@ -794,9 +803,15 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 // (select chain: a runtime index into the by-value parameter block would spill it)
                 {
                     T qi = T(0);
+                    if (PIN) {
+                        const T* gn = reinterpret_cast<const T*>(a.noise) + inst * NOISE_WORDS;
+                        if (i >= 3 && i < 15) qi = gn[i - 3];
+                        if (i == 17) qi = gn[12];
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 12; ++k) qi = (i == 3 + k) ? prm.qd[k] : qi;
-                    qi = (i == 17) ? prm.qd[12] : qi;
+                        for (int k = 0; k < 12; ++k) qi = (i == 3 + k) ? prm.qd[k] : qi;
+                        qi = (i == 17) ? prm.qd[12] : qi;
+                    }
                     if (i >= 3) sP[i * PS + i] += qi;
                 }
                 // P'cc[a2][b2] and P'cc[a2][3 + b2]
@@ -817,7 +832,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                     const T* N6 = sJ + J_N6;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const T nk = N6[3 * a2 + k] * prm.qd[3 + k];
+                        const T nk = N6[3 * a2 + k] * (PIN ? reinterpret_cast<const T*>(a.noise)[inst * NOISE_WORDS + 3 + k] : prm.qd[3 + k]);
                         x += nk * N6[3 * b2 + k];
                         y += nk * N6[3 * (3 + b2) + k];
                     }
@@ -845,7 +860,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 if (prm.q_gyro) {   // Fi[6:9,3:6] = I couples the gyro noise into the camera rows
                     const T* N6 = sJ + J_N6;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) row[6 + k] += N6[3 * ar + k] * prm.qd[3 + k];
+                    for (int k = 0; k < 3; ++k) row[6 + k] += N6[3 * ar + k] * (PIN ? reinterpret_cast<const T*>(a.noise)[inst * NOISE_WORDS + 3 + k] : prm.qd[3 + k]);
                 }
 #pragma unroll
                 for (int k = 0; k < 18; ++k) {
@@ -869,7 +884,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
 #pragma unroll
             for (int i = 0; i < 7; ++i)
 #pragma unroll
-                for (int j = 0; j <= i; ++j) S[i * (i + 1) / 2 + j] = sP[sel[i] * PS + sel[j]] + (i == j ? prm.r[i] : T(0));
+                for (int j = 0; j <= i; ++j) S[i * (i + 1) / 2 + j] = sP[sel[i] * PS + sel[j]] + (i == j ? (PIN ? reinterpret_cast<const T*>(a.noise)[inst * NOISE_WORDS + 13 + i] : prm.r[i]) : T(0));
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 T dj = S[j * (j + 1) / 2 + j];
@@ -1798,7 +1813,7 @@ __global__ __launch_bounds__(256) void eskf_log_rows_kernel(int64_t B, const T* 
 // ----------------------------------------------------------------------------------
 // host-side launchers
 // ----------------------------------------------------------------------------------
-template <typename T, int LPI>
+template <typename T, int LPI, bool PIN = false>
 static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
     // rounds per wave: enough waves to keep every CU's LDS full several times over, few enough
@@ -1810,7 +1825,7 @@ static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipSt
     b.rounds = rounds;
     blocks = (a.B + (int64_t)G * rounds - 1) / ((int64_t)G * rounds);
     if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((eskf_cov_kernel<T, LPI>), dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
+    hipLaunchKernelGGL((eskf_cov_kernel<T, LPI, PIN>), dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
     return hipGetLastError();
 }
 
@@ -1837,7 +1852,8 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 2. covariance: LPI lanes per instance
+    // 2. covariance.  Per-instance noise is implemented by the LDS-image kernel (32 lanes per instance)
+    if (a.noise) return launch_cov_t<T, 32, true>(a, prm, stream);
     switch (lpi) {
         case 1:  // DVI_ESKF_LANES_ROWS; the gain matrix is only formed by the LDS-image kernel
             e = a.K_out ? launch_cov_t<T, 32>(a, prm, stream) : launch_cov_rows<T>(a, prm, stream);

@@ -120,6 +120,56 @@ class Simulator:
         print(f"\nglobal minimum using params: {ret.x},\nmse = {ret.fun:.3f}")
         self._dof_mse = ret.fun
 
+    def evaluate_population(self, candidates) -> np.ndarray:
+        """DOF MSE of every candidate noise setting from ONE batched run: row i of
+        ``candidates`` holds the std-devs of ``optim_std`` (process random-walk std 0:7, measurement
+        std 7:); candidate i becomes filter instance i with its own diag(Q) / diag(R)
+        (``dvi_eskf_set_noise_per_instance``).  Same noise matrices as ``optim_func`` of ``optimise``
+        (Simulator.py:163-245) builds for one candidate; the cost is ``Filter.calculate_dof_metric``
+        (Filter.py:452-455) -- in v1 the assignment of ``kf.mse`` is commented out (Filter.py:168), so the
+        reference's own cost is identically 0."""
+        import torch
+
+        from .batch import BatchedESKF
+        from .schedule import build_run_inputs
+        X = np.atleast_2d(np.asarray(candidates, dtype=float))
+        S = X.shape[0]
+        kf = self.kf
+        ri = build_run_inputs(self.config, self.camera, self.imu, self.probe)
+        q = np.tile(np.diag(kf.Q).astype(float), (S, 1))
+        q[:, 0:3] = kf._dt ** 2 * kf.stdev_na ** 2                  # Filter.update_noise_matrices (Filter.py:110-117)
+        q[:, 3:6] = kf._dt ** 2 * kf.stdev_nom ** 2
+        q[:, 6:13] = np.square(X[:, 0:7])
+        # R stays as it is: the optim_std setter (Simulator.py:76-86) stores val[7:8] as the measurement
+        # std-dev but never recomputes meas_noise_var, so the tuning loop of v1 only moves Q[6:13]
+        r = np.tile(np.diag(kf.R).astype(float), (S, 1))
+        dev = BatchedESKF(S, length=self.sym_probe.scope_length, theta_cam=self.sym_probe.theta_cam,
+                          frozen=[bool(f) for f in self.config.frozen_dofs], sigma_a=kf.stdev_na, sigma_om=kf.stdev_nom,
+                          hold_frozen=bool(getattr(self.config, "golden_compat", False)))
+        dev.set_noise_per_instance(q, r)
+        dev.set_state(x=np.tile(ri.x0, (S, 1)), P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+        ip = 0
+        for k in range(len(ri.t_meas)):
+            n = int(ri.n_pred[k])
+            dev.epoch(ri.dt[ip:ip + n], ri.om[ip:ip + n], ri.acc[ip:ip + n], ri.pos[k], ri.quat[k], ri.notch[k])
+            ip += n
+        gt = torch.as_tensor(np.asarray(self.config.gt_imu_dofs, dtype=float), device=dev.device)
+        d = dev.calibration() - gt
+        return ((d * d).sum(dim=1) / 6).cpu().numpy()               # Filter.calculate_dof_metric (Filter.py:452-455)
+
+    def optimise_population(self, popsize: int = 4, maxiter: int = 1, seed: int = 0):
+        """``optimise`` with every generation of the differential evolution evaluated as one batch on
+        the GPU (scipy's vectorised, deferred-updating mode) instead of one filter run per candidate."""
+        from scipy.optimize import differential_evolution
+        d = np.deg2rad
+        bounds = ((0, 10),) * 3 + ((0, d(5)),) * 4 + ((0, 0.2),) * 3 + ((0, d(10)),) * 3 + ((0, d(1)),)
+        ret = differential_evolution(lambda X: self.evaluate_population(np.asarray(X).T), bounds, strategy="best1bin",
+                                     maxiter=maxiter, popsize=popsize, updating="deferred", vectorized=True, seed=seed,
+                                     polish=False)
+        print(f"\nglobal minimum using params: {ret.x},\nmse = {ret.fun:.3f}")
+        self._dof_mse = ret.fun
+        return ret
+
     def plot(self, compact=True) -> None:
         kf = self._kf_best if self._kf_best else self.kf
         kf.plot(self.camera, compact=compact)

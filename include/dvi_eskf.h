@@ -83,6 +83,15 @@ int dvi_eskf_dtype(const dvi_eskf* h);
  * diagonal Q and R); otherwise DVI_ESKF_EINVAL. */
 int dvi_eskf_set_noise(dvi_eskf* h, const double* Q13x13, const double* R7x7);
 
+/* A population of differently tuned filters in one batch (Simulator.optimise,
+ * Simulator.py:163-245, evaluates one candidate of the differential evolution per run -- here one
+ * candidate per instance).  HOST arrays: q13 [B,13] = diag(Q) and r7 [B,7] = diag(R) per instance
+ * (Filter.py:67-75,110-117), sigma_om3 [B,3] = the gyro noise std-dev at which the Jacobians are
+ * evaluated (Filter.py:330-333) or NULL to keep the one of dvi_eskf_create.  Steps then run through
+ * the LDS-image covariance kernel; dvi_eskf_set_noise returns to one model for the whole batch. */
+int dvi_eskf_set_noise_per_instance(dvi_eskf* h, const double* q13, const double* r7, const double* sigma_om3,
+                                    void* stream);
+
 /* Filter.reset / the _states, _P, om_old, acc_old, R_WB_old attributes (Filter.py:44-45,
  * 78-80,95-108).  x26 [B,26], P576 [B,24,24] (symmetric; the lower triangle is stored),
  * om_old3 / acc_old3 [B,3]; q_old4 [B,4] is the attitude whose rotation matrix is

@@ -1,0 +1,94 @@
+"""a population of differently tuned filters in one batch (per-instance diag(Q), diag(R),
+sigma_om) against (i) one single-model filter per candidate and (ii) the C oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from tests.helpers import default_run
+from tests.test_gpu_parity import _make, _perturbed_x0, _rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _population(Q, R, so, n, rng, gyro):
+    q = np.tile(np.diag(Q), (n, 1)) * rng.uniform(0.3, 3.0, (n, 13))
+    if gyro:
+        q[:, 3:6] = rng.uniform(1e-6, 1e-4, (n, 3))
+    r = np.tile(np.diag(R), (n, 1)) * rng.uniform(0.3, 3.0, (n, 7))
+    s = np.tile(so, (n, 1)) * rng.uniform(0.5, 2.0, (n, 3))
+    return q, r, s
+
+
+@pytest.mark.parametrize("gyro", [False, True])
+def test_population_equals_one_filter_per_candidate(gyro):
+    n = 6
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    rng = np.random.default_rng(11)
+    q, r, s = _population(Q, R, np.asarray(so, dtype=float), n, rng, gyro)
+    x0 = _perturbed_x0(ri, n)
+    pop = _make(cfg, ri, Q, R, sa, so, n, False, x0)
+    pop.set_noise_per_instance(q, r, s)
+    singles = []
+    for i in range(n):
+        f = _make(cfg, ri, np.diag(q[i]), np.diag(r[i]), sa, s[i], 1, False, x0[i:i + 1], lpi=32)
+        singles.append(f)
+    oracles = []
+    for i in range(n):
+        prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, False, sa, s[i], np.diag(q[i]), np.diag(r[i]))
+        oracles.append(c_oracle.OracleBatch(prm, x0[i:i + 1], ri.P0, ri.om0, ri.acc0))
+    ip = 0
+    for k in range(3):
+        for _ in range(ri.n_pred[k]):
+            pop.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            for f, o in zip(singles, oracles):
+                f.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+                o.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            ip += 1
+        st, _ = pop.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        assert (st.cpu().numpy() == 0).all()
+        for f, o in zip(singles, oracles):
+            f.update(ri.pos[k], ri.quat[k], ri.notch[k])
+            o.update(ri.pos[k], ri.quat[k], ri.notch[k])
+    a = pop.get_state()
+    for i, (f, o) in enumerate(zip(singles, oracles)):
+        b = f.get_state()
+        for key in ("x", "P"):
+            assert torch.equal(a[key][i], b[key][0]), (i, key)          # same kernel, same arithmetic
+        assert _rel(a["x"][i].cpu().numpy(), o.x[0], 1) <= 1e-9         # three frames of free running
+        assert _rel(a["P"][i].cpu().numpy(), o.P[0], 1) <= 1e-8
+    # candidates differ from one another, and a clone carries the population along
+    assert not torch.equal(a["P"][0], a["P"][1])
+    c = pop.clone()
+    pop.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+    c.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+    assert torch.equal(pop.get_state()["P"], c.get_state()["P"])
+    # back to one model for the whole batch
+    pop.set_noise(Q, R)
+    pop.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+    assert torch.isfinite(pop.get_state()["P"]).all()
+
+
+def test_simulator_population_matches_one_run_per_candidate(tmp_path):
+    """Simulator.evaluate_population: the DOF metric of every candidate of the tuning loop from one
+    batched run == the metric after one reference-shaped Filter run per candidate."""
+    from dvi_ekf_amd import Simulator
+    from tests.test_gpu_filter_api import _config
+    cfg = _config(tmp_path, False)
+    cfg.frozen_dofs = [0, 0, 0, 0, 0, 0]
+    sim = Simulator(cfg)
+    base = np.asarray(sim.optim_std, dtype=float)
+    rng = np.random.default_rng(5)
+    cands = base[None, :] * rng.uniform(0.5, 2.0, (4, base.size))
+    cands[0] = base
+    batched = sim.evaluate_population(cands)
+    assert batched.shape == (4,) and np.isfinite(batched).all()
+    one_by_one = []
+    for c in cands:
+        s1 = Simulator(cfg)                 # (a fresh one per candidate: the reference's reset_kf re-uses the IMU log)
+        s1.optim_std = list(c)
+        s1.kf.run(s1.camera, 0, "candidate")
+        one_by_one.append(s1.kf.calculate_dof_metric())
+    one_by_one = np.array(one_by_one)
+    assert np.abs(batched - one_by_one).max() <= 1e-9 * max(1.0, np.abs(one_by_one).max())
+    assert len(set(np.round(batched, 12))) > 1          # the candidates do differ
