@@ -543,6 +543,10 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
     }
     if (!live) return;
+    // (output addresses are formed here, from an opaque copy of the instance index: formed in the
+    // prologue they would sit in registers -- in scratch, in fact -- through the whole propagation)
+    int64_t bo = b;
+    asm volatile("" : "+v"(bo));
     if (a.do_update) {
         // measurement correction and residual (Filter.py:364-375)
         const T gpos[3] = {sM[0], sM[1], sM[2]};
@@ -561,13 +565,13 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         if (nv > T(1)) { nv = T(1); flag = T(1); }
         const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
         const T f = (nv == T(0)) ? T(0) : ang / nv;
-        T* gr = reinterpret_cast<T*>(a.res) + b * 8;
+        T* gr = reinterpret_cast<T*>(a.res) + bo * 8;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { gr[i] = gpos[i] - s.pc[i]; gr[3 + i] = f * qe[i]; }
         gr[6] = ang_notch - s.notch[0];
         gr[7] = flag;                                         // asin argument was clamped
     }
-    if (a.n_pred > 0 || a.apply_pending) store_state(xs, a.B, b, s);
+    if (a.n_pred > 0 || a.apply_pending) store_state(xs, a.B, bo, s);
 }
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
