@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident; 64/32/24/16/12/8 = LDS-image kernel with that many lanes per instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
+    ap.add_argument("--per-instance-noise", action="store_true",
+                    help="diagnostic: every instance carries its own (identical) noise record -- the tuning-population path")
     ap.add_argument("--mode", default="pair", choices=["pair", "predict", "update"],
                     help="diagnostic: time only the predict or only the update launch (not the metric)")
     args = ap.parse_args()
@@ -105,6 +107,8 @@ def main():
     f = wl.make_filter()
     if args.lanes:
         f.set_lanes_per_instance(args.lanes)
+    if args.per_instance_noise:
+        f.set_noise_per_instance(np.tile(np.diag(wl.Q), (B, 1)), np.tile(np.diag(wl.R), (B, 1)))
     snap = f.clone()
     status = torch.zeros(B, dtype=torch.int32, device=dev)
 

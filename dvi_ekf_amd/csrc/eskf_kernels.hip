@@ -1066,8 +1066,9 @@ constexpr int R_BUF = 0;           // 24 x 25 exchange image | [24][XS] panel of
 constexpr int R_C = 600;           // two 24-word column buffers (alternating)
 constexpr int R_J = 648;           // Jacobian record, blocks re-laid on even offsets (16-byte reads)
 constexpr int L_A = 0, L_TH = 10, L_BM = 20, L_CM = 30, L_DM = 48, L_EM = 60, L_DT = 70, L_N6 = 72;
-constexpr int R_RES = 744;         // residual of the update (7) + non-finite flag
+constexpr int R_RES = 744;         // residual of the update (7) + non-finite flag [+ the instance's noise record, 24 words]
 constexpr int R_REGION = 752;      // words per instance (even)
+constexpr int R_REGION_PIN = 776;  // with per-instance noise
 __device__ __forceinline__ int lds_word(int e) {   // HBM record word -> LDS word
     return e + (e >= J_TH) + (e >= J_BM) + (e >= J_CM) + (e >= J_DT) + (e >= J_N6);
 }
@@ -1281,11 +1282,20 @@ __device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[2
 // P' += Fi Q Fi^T on the row-resident P: diagonal entries 3..14 <- Q[i-3], 17 <- Q[12]
 // (Filter.py:263-264,349); with gyro noise (tune mode) also the camera rows through N6 and theta
 // through Fi[6:9,3:6] = I
-template <typename T>
-__device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, int row, T (&p)[24]) {
+template <typename T, bool PIN>
+__device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, const T* sN, int row, T (&p)[24]) {
+    if (PIN) {      // diag(Q) of this instance sits in LDS (sN[0:13]); each lane needs the entry of its own row
+        T qrow = T(0);
+        if (row >= 3 && row < 15) qrow = sN[row - 3];
+        if (row == 17) qrow = sN[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? prm.qd[k] : T(0);
-    p[17] += (row == 17) ? prm.qd[12] : T(0);
+        for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? qrow : T(0);
+        p[17] += (row == 17) ? qrow : T(0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? prm.qd[k] : T(0);
+        p[17] += (row == 17) ? prm.qd[12] : T(0);
+    }
     if (prm.q_gyro) {
         const T* N6 = sJ + L_N6;
         if (row >= 18) {
@@ -1293,7 +1303,7 @@ __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ,
             T na[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                na[k] = N6[3 * ar + k] * prm.qd[3 + k];
+                na[k] = N6[3 * ar + k] * (PIN ? sN[3 + k] : prm.qd[3 + k]);
                 p[6 + k] += na[k];
             }
 #pragma unroll
@@ -1302,7 +1312,7 @@ __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ,
                 for (int k = 0; k < 3; ++k) p[18 + b] += na[k] * N6[3 * b + k];
         } else if (row >= 6 && row < 9) {
             const int k = row - 6;
-            const T qk = (k == 0) ? prm.qd[3] : (k == 1) ? prm.qd[4] : prm.qd[5];
+            const T qk = PIN ? sN[3 + k] : ((k == 0) ? prm.qd[3] : (k == 1) ? prm.qd[4] : prm.qd[5]);
 #pragma unroll
             for (int b = 0; b < 6; ++b) p[18 + b] += N6[3 * b + k] * qk;
         }
@@ -1323,11 +1333,14 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 #ifndef ROWS_WAVES
 #define ROWS_WAVES 3
 #endif
-template <typename T>
+// PIN: per-instance noise (diag(Q), diag(R) from the instance's noise record, staged into LDS with the
+// residual) instead of the parameter block
+template <typename T, bool PIN = false>
 __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     using namespace rowk;
     constexpr int LPI = 32, G = 2;
-    __shared__ __attribute__((aligned(16))) T smem[G * R_REGION];
+    constexpr int REGION = PIN ? R_REGION_PIN : R_REGION;
+    __shared__ __attribute__((aligned(16))) T smem[G * REGION];
 
     const int lane = threadIdx.x;
     const int grp = lane >> 5;
@@ -1335,10 +1348,11 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     const bool active = lig < 24;
     const int row0 = active ? lig : 23;     // idle lanes shadow row 23 and write nothing
 
-    T* sB = smem + grp * R_REGION + R_BUF;
-    T* sC = smem + grp * R_REGION + R_C;
-    T* sJ = smem + grp * R_REGION + R_J;
-    T* sR = smem + grp * R_REGION + R_RES;
+    T* sB = smem + grp * REGION + R_BUF;
+    T* sC = smem + grp * REGION + R_C;
+    T* sJ = smem + grp * REGION + R_J;
+    T* sR = smem + grp * REGION + R_RES;
+    const T* sN = sR + 8;                   // PIN: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
     // where the words of the packed record live in the image: ten positions per lane (five 16-byte
     // pieces of two words), worked out once per wave and read back each round -- the index
     // arithmetic (a division by 25 per word) would otherwise be redone or carried in registers
@@ -1389,7 +1403,10 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             const int w = lj_ + k * LPI;                                                           \
             DST[k] = gJ_[w < JW ? w : JW - 1];                                                     \
         }                                                                                          \
-        RES = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                  \
+        if (PIN && lj_ >= 8)                                                                       \
+            RES = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + lj_ - 8];    \
+        else                                                                                       \
+            RES = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];              \
     }
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
@@ -1397,7 +1414,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             const int w = lig + k * LPI;                                                           \
             sJ[lds_word(w < JW ? w : JW - 1)] = SRC[k];                                            \
         }                                                                                          \
-        sR[lig & 7] = RES;                                                                         \
+        sR[PIN ? lig : (lig & 7)] = RES;                                                           \
     }
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
 #define ESKF_UNPACK_ROW()                                                                          \
@@ -1418,7 +1435,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         fx_apply_store(sJ, p, sB + row * PS, active);   /* column `row` of Fx P = row `row` of W = P Fx^T */ \
         group_sync();                                                                              \
         fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */          \
-        noise_rows(prm, sJ, row, p);                                                               \
+        noise_rows<T, PIN>(prm, sJ, sN, row, p);                                                               \
         group_sync();                                                                              \
     }
     {   // first instance of this wave: packed covariance into registers, first records into LDS
@@ -1475,7 +1492,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             T c[12];
 #pragma unroll
             for (int j = 0; j < 12; ++j) c[j] = cb[12 + j];
-            const T sv = c[sel[m] - 12] + prm.r[m];
+            const T sv = c[sel[m] - 12] + (PIN ? sN[13 + m] : prm.r[m]);
             fail = fail || !(sv != T(0) && t_finite(sv));
             if (!fail) {
                 const T g = fast_rcp(sv);
@@ -1506,7 +1523,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             for (int m = 6; m >= 0; --m) {
                 if (m < napplied) {
                     const T* cb = sB + m * 24;
-                    const T g = fast_rcp(cb[sel[m]] + prm.r[m]);
+                    const T g = fast_rcp(cb[sel[m]] + (PIN ? sN[13 + m] : prm.r[m]));
                     const T kk = cb[row] * g;
 #pragma unroll
                     for (int j = 0; j < 24; ++j) p[j] += kk * cb[j];
@@ -1833,7 +1850,7 @@ static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipSt
     return hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool PIN = false>
 static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 2;
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
@@ -1844,7 +1861,7 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     b.rounds = rounds;
     blocks = (a.B + (int64_t)G * rounds - 1) / ((int64_t)G * rounds);
     if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(eskf_cov_rows_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
+    hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN>), dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
     return hipGetLastError();
 }
 
@@ -1856,8 +1873,10 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // 2. covariance.  Per-instance noise is implemented by the LDS-image kernel (32 lanes per instance)
-    if (a.noise) return launch_cov_t<T, 32, true>(a, prm, stream);
+    // 2. covariance.  With per-instance noise: the PIN variants (row-resident, or the LDS-image kernel
+    // with 32 lanes per instance when the gain matrix is asked for or that kernel is selected)
+    if (a.noise)
+        return (lpi == 1 && !a.K_out) ? launch_cov_rows<T, true>(a, prm, stream) : launch_cov_t<T, 32, true>(a, prm, stream);
     switch (lpi) {
         case 1:  // DVI_ESKF_LANES_ROWS; the gain matrix is only formed by the LDS-image kernel
             e = a.K_out ? launch_cov_t<T, 32>(a, prm, stream) : launch_cov_rows<T>(a, prm, stream);

@@ -20,18 +20,20 @@ def _population(Q, R, so, n, rng, gyro):
     return q, r, s
 
 
-@pytest.mark.parametrize("gyro", [False, True])
-def test_population_equals_one_filter_per_candidate(gyro):
+@pytest.mark.parametrize("gyro,lpi", [(False, 1), (True, 1), (False, 32), (True, 32)])
+def test_population_equals_one_filter_per_candidate(gyro, lpi):
+    """lpi = 1: row-resident kernel (noise record staged into LDS), 32: LDS-image kernel; the single-model
+    filters run the same kernel with the noise in the parameter block."""
     n = 6
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
     rng = np.random.default_rng(11)
     q, r, s = _population(Q, R, np.asarray(so, dtype=float), n, rng, gyro)
     x0 = _perturbed_x0(ri, n)
-    pop = _make(cfg, ri, Q, R, sa, so, n, False, x0)
+    pop = _make(cfg, ri, Q, R, sa, so, n, False, x0, lpi=lpi)
     pop.set_noise_per_instance(q, r, s)
     singles = []
     for i in range(n):
-        f = _make(cfg, ri, np.diag(q[i]), np.diag(r[i]), sa, s[i], 1, False, x0[i:i + 1], lpi=32)
+        f = _make(cfg, ri, np.diag(q[i]), np.diag(r[i]), sa, s[i], 1, False, x0[i:i + 1], lpi=lpi)
         singles.append(f)
     oracles = []
     for i in range(n):
