@@ -37,6 +37,10 @@ def test_error_codes_instead_of_exceptions():
     assert L.dvi_eskf_create(C.byref(p), 0, 0, 0, C.byref(h)) == -1           # batch must be positive
     assert L.dvi_eskf_create(C.byref(p), 4, 7, 0, C.byref(h)) == -1           # unknown dtype
     assert L.dvi_eskf_create(C.byref(p), 4, 0, 4096, C.byref(h)) == -2        # no such device
+    assert L.dvi_eskf_log_rows(f._h, 0.0, None, None) == -1                   # no output buffer
+    assert L.dvi_eskf_set_noise_per_instance(f._h, None, None, None, None) == -1
+    qn = np.full((4, 13), np.nan)
+    assert L.dvi_eskf_set_noise_per_instance(f._h, qn.ctypes.data_as(dp), np.ones((4, 7)).ctypes.data_as(dp), None, None) == -1
     with pytest.raises(_capi.EskfError):
         f.set_noise(Qbad, None)
     # the handle is still usable
