@@ -1374,11 +1374,12 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
 
-    // instance indices are 32-bit (the launcher refuses B >= 2^31) and made opaque once per round:
-    // byte addresses are formed where they are used instead of being carried as 64-bit induction
-    // variables through the round
+    // one wavefront = two instances, start to finish (waves that loop over several instances with a
+    // register prefetch of the next record were measured 2 % slower at three waves per SIMD: the other
+    // waves cover the HBM latency, and 32 768 short blocks balance better than 8 192 long ones).
+    // Instance indices are 32-bit (the launcher refuses B >= 2^31) and opaque: byte addresses are
+    // formed where they are used instead of being kept in registers from the prologue on.
     const int nB = (int)a.B;
-    const int round_stride = (int)gridDim.x * G;
     const int slot = (int)blockIdx.x * G + grp;
     T2 pv[NV];
 #define ESKF_ISSUE_LOADS(INST)                                                                     \
@@ -1438,20 +1439,16 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         noise_rows<T, PIN>(prm, sJ, sN, row, p);                                                               \
         group_sync();                                                                              \
     }
-    {   // first instance of this wave: packed covariance into registers, first records into LDS
-        const int i0 = slot < nB ? slot : nB - 1;
-        ESKF_ISSUE_LOADS(i0)
+    const bool valid = slot < nB;           // tail: recompute the last instance, write nothing
+    int inst = valid ? slot : nB - 1;
+    int row = row0;
+    asm volatile("" : "+v"(row), "+v"(inst));
+    {   // packed covariance into registers, first Jacobian record and residual into LDS
+        ESKF_ISSUE_LOADS(inst)
         T j0[NJ], r0 = T(0);
-        ESKF_LOAD_J(j0, r0, i0, 0)
+        ESKF_LOAD_J(j0, r0, inst, 0)
         ESKF_STAGE_J(j0, r0)
     }
-
-  for (int rnd = 0; rnd < a.rounds; ++rnd) {
-    const int inst_raw = rnd * round_stride + slot;
-    const bool valid = inst_raw < nB;       // tail: recompute the last instance, write nothing
-    int inst = valid ? inst_raw : nB - 1;
-    int row = row0;                         // per-lane addresses are recomputed per round, not kept in registers
-    asm volatile("" : "+v"(row), "+v"(inst));
 
     constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
     T p[24];                                // row `row` of P
@@ -1601,22 +1598,6 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
 #pragma unroll
         for (int j = 0; j < 24; ++j) sB[row * PS + j] = p[j];
     }
-    // the row is in LDS now: its registers take the next round's records (issued here, consumed at
-    // the top of the next round; the other waves of the SIMD cover the rest of the HBM latency)
-    asm volatile("" : : : "memory");        // (the loads below are not to be hoisted into the reset)
-    if (rnd + 1 < a.rounds) {
-        const int nraw = (rnd + 1) * round_stride + slot;
-        const int ni = nraw < nB ? nraw : nB - 1;
-        ESKF_ISSUE_LOADS(ni)
-        T jnext[NJ], rnext = T(0);
-        ESKF_LOAD_J(jnext, rnext, ni, 0)
-        ESKF_STAGE_J(jnext, rnext)          // (the Jacobian and residual areas are idle since the update)
-    } else {
-        // (defined on every path: otherwise the registers of the record consumed at the top of
-        // this round stay reserved through the whole round for the case that nothing is fetched)
-#pragma unroll
-        for (int k = 0; k < NV; ++k) { pv[k].x = T(0); pv[k].y = T(0); }
-    }
     group_sync();
     if (valid) {
         T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
@@ -1634,8 +1615,6 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
             }
         }
     }
-    group_sync();   // the next round overwrites the image
-  }
 #undef ESKF_ISSUE_LOADS
 #undef ESKF_LOAD_J
 #undef ESKF_STAGE_J
@@ -1854,14 +1833,8 @@ template <typename T, bool PIN = false>
 static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 2;
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
-    StepArgs b = a;
-    int64_t blocks = (a.B + G - 1) / G;
-    int rounds = 1;
-    while (rounds < 4 && blocks / (rounds * 2) >= 256 * 16) rounds *= 2;
-    b.rounds = rounds;
-    blocks = (a.B + (int64_t)G * rounds - 1) / ((int64_t)G * rounds);
-    if (blocks > 0x7fffffff) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN>), dim3((unsigned)blocks), dim3(64), 0, stream, b, prm);
+    const int64_t blocks = (a.B + G - 1) / G;               // one wavefront per two instances
+    hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
     return hipGetLastError();
 }
 
