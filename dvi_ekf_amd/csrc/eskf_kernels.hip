@@ -1329,6 +1329,33 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 }
 }  // namespace rowk
 
+// Index tables of the row-resident kernel, computed at compile time and read from device memory (a few
+// cached 16-byte loads per lane instead of ~200 integer instructions per wave):
+//   pos[lig][10]   image position (word offset i*25 + j) of the ten packed-record words lane lig moves
+//                  (pieces lig, lig+32, ... of 16 bytes; the last piece is clamped to the record's end)
+//   gat[row][24]   image position of P[row][j] in the lower-triangle image: max(row,j)*25 + min(row,j)
+struct RowsTables {
+    int pos[32][12];
+    int gat[24][24];
+};
+constexpr int packed_image_pos(int e) {      // packed word e -> i*25 + j with i >= j (see unpack_ij)
+    const int r = e / 25, c = e - 25 * r;
+    return (c <= r) ? (r * 25 + c) : ((23 - r) * 25 + (c - r - 1));
+}
+constexpr RowsTables make_rows_tables() {
+    RowsTables t{};
+    for (int l = 0; l < 32; ++l)
+        for (int k = 0; k < 5; ++k) {
+            const int e2r = l + 32 * k, e2 = e2r < 150 ? e2r : 149;
+            t.pos[l][2 * k] = packed_image_pos(2 * e2);
+            t.pos[l][2 * k + 1] = packed_image_pos(2 * e2 + 1);
+        }
+    for (int r = 0; r < 24; ++r)
+        for (int j = 0; j < 24; ++j) t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
+    return t;
+}
+__device__ const RowsTables kRowsTables = make_rows_tables();
+
 // waves per SIMD the row-resident kernel is built for: 3 (<= 168 VGPRs; it needs 162)
 #ifndef ROWS_WAVES
 #define ROWS_WAVES 3
@@ -1353,23 +1380,6 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     T* sJ = smem + grp * REGION + R_J;
     T* sR = smem + grp * REGION + R_RES;
     const T* sN = sR + 8;                   // PIN: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
-    // where the words of the packed record live in the image: ten positions per lane (five 16-byte
-    // pieces of two words), worked out once per wave and read back each round -- the index
-    // arithmetic (a division by 25 per word) would otherwise be redone or carried in registers
-    constexpr int OS = 12;                  // table row stride (ints): 16-byte aligned rows
-    __shared__ __attribute__((aligned(16))) int sOff[LPI * OS];
-    if (grp == 0) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int e2r = lig + k * LPI, e2 = e2r < 150 ? e2r : 149;
-            int i, j;
-            unpack_ij(2 * e2, i, j);
-            sOff[lig * OS + 2 * k] = i * PS + j;
-            unpack_ij(2 * e2 + 1, i, j);
-            sOff[lig * OS + 2 * k + 1] = i * PS + j;
-        }
-    }
-
     constexpr int NJ = (J_FULL + LPI - 1) / LPI;
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
@@ -1420,14 +1430,15 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
-        int off_[2 * NV];                                                                          \
-        _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = sOff[lig * OS + k];           \
+        int off_[2 * NV], gat_[24];                                                                \
+        _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = kRowsTables.pos[lig][k];      \
+        _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gat[row][j];          \
         _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
             sB[off_[2 * k]] = pv[k].x;                                                             \
             sB[off_[2 * k + 1]] = pv[k].y;                                                         \
         }                                                                                          \
         group_sync();                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[(j <= row) ? row * PS + j : j * PS + row]; \
+        _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[gat_[j]];                         \
         group_sync();                                                                              \
     }
     // one predict on the row-resident P with the Jacobian record that sits in LDS
@@ -1603,7 +1614,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
         int off[2 * NV];
 #pragma unroll
-        for (int k = 0; k < 2 * NV; ++k) off[k] = sOff[lig * OS + k];
+        for (int k = 0; k < 2 * NV; ++k) off[k] = kRowsTables.pos[lig][k];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e2 = lig + k * LPI;
