@@ -1337,6 +1337,8 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 struct RowsTables {
     int pos[32][12];
     int gat[24][24];
+    int jsrc[32][4];    // Jacobian record: the three record words lane lig moves (clamped to the record) ...
+    int jdst[32][4];    // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
 };
 constexpr int packed_image_pos(int e) {      // packed word e -> i*25 + j with i >= j (see unpack_ij)
     const int r = e / 25, c = e - 25 * r;
@@ -1352,6 +1354,12 @@ constexpr RowsTables make_rows_tables() {
         }
     for (int r = 0; r < 24; ++r)
         for (int j = 0; j < 24; ++j) t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
+    for (int l = 0; l < 32; ++l)
+        for (int k = 0; k < 3; ++k) {
+            const int wr = l + 32 * k, w = wr < 88 ? wr : 87;
+            t.jsrc[l][k] = w;
+            t.jdst[l][k] = w + (w >= 9) + (w >= 18) + (w >= 27) + (w >= 66) + (w >= 67);
+        }
     return t;
 }
 __device__ const RowsTables kRowsTables = make_rows_tables();
@@ -1410,10 +1418,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         int lj_ = lig;                                                                             \
         asm volatile("" : "+v"(lj_));   /* (per-lane addresses formed here, not kept across rounds) */ \
         const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
-        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w = lj_ + k * LPI;                                                           \
-            DST[k] = gJ_[w < JW ? w : JW - 1];                                                     \
-        }                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < NJ; ++k) DST[k] = gJ_[kRowsTables.jsrc[lj_][k]];     \
         if (PIN && lj_ >= 8)                                                                       \
             RES = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + lj_ - 8];    \
         else                                                                                       \
@@ -1421,10 +1426,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     }
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
-        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w = lig + k * LPI;                                                           \
-            sJ[lds_word(w < JW ? w : JW - 1)] = SRC[k];                                            \
-        }                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < NJ; ++k) sJ[kRowsTables.jdst[lig][k]] = SRC[k];      \
         sR[PIN ? lig : (lig & 7)] = RES;                                                           \
     }
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
