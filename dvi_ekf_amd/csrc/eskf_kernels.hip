@@ -1388,6 +1388,9 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     T* sJ = smem + grp * REGION + R_J;
     T* sR = smem + grp * REGION + R_RES;
     const T* sN = sR + 8;                   // PIN: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
+    // last word of the record in use (dt without the gyro block of Q, else the end of N6) and its LDS slot
+    const int jlast = prm.q_gyro ? J_FULL - 1 : J_CORE - 1;
+    const int jlast_lds = prm.q_gyro ? L_N6 + 17 : L_DT;
     constexpr int NJ = (J_FULL + LPI - 1) / LPI;
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
@@ -1418,7 +1421,10 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         int lj_ = lig;                                                                             \
         asm volatile("" : "+v"(lj_));   /* (per-lane addresses formed here, not kept across rounds) */ \
         const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
-        _Pragma("unroll") for (int k = 0; k < NJ; ++k) DST[k] = gJ_[kRowsTables.jsrc[lj_][k]];     \
+        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
+            const int w_ = kRowsTables.jsrc[lj_][k];                                               \
+            DST[k] = gJ_[w_ < jlast ? w_ : jlast];   /* (the padding of the record is not fetched) */ \
+        }                                                                                          \
         if (PIN && lj_ >= 8)                                                                       \
             RES = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + lj_ - 8];    \
         else                                                                                       \
@@ -1426,7 +1432,10 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     }
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
-        _Pragma("unroll") for (int k = 0; k < NJ; ++k) sJ[kRowsTables.jdst[lig][k]] = SRC[k];      \
+        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
+            const int w_ = kRowsTables.jdst[lig][k];                                               \
+            sJ[w_ < jlast_lds ? w_ : jlast_lds] = SRC[k];                                          \
+        }                                                                                          \
         sR[PIN ? lig : (lig & 7)] = RES;                                                           \
     }
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
