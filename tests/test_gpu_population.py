@@ -94,3 +94,31 @@ def test_simulator_population_matches_one_run_per_candidate(tmp_path):
     one_by_one = np.array(one_by_one)
     assert np.abs(batched - one_by_one).max() <= 1e-9 * max(1.0, np.abs(one_by_one).max())
     assert len(set(np.round(batched, 12))) > 1          # the candidates do differ
+
+
+def test_population_fp32_and_tiny_batches():
+    """The per-instance-noise variants also exist in fp32, and batch sizes below one wavefront's two
+    instances (B = 1, 2, 3) behave like the same instances inside a larger batch."""
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    rng = np.random.default_rng(2)
+    n = 5
+    q, r, s = _population(Q, R, np.asarray(so, dtype=float), n, rng, False)
+    x0 = _perturbed_x0(ri, n)
+    f64 = _make(cfg, ri, Q, R, sa, so, n, False, x0)
+    f32 = _make(cfg, ri, Q, R, sa, so, n, False, x0, dtype=torch.float32)
+    for f in (f64, f32):
+        f.set_noise_per_instance(q, r, s)
+        f.predict(ri.dt[0], ri.om[0], ri.acc[0])
+    a, b = f64.get_state(), f32.get_state()
+    assert float((a["x"] - b["x"].double()).abs().max()) <= 2e-5 * max(1.0, float(a["x"].abs().max()))
+    assert float(((a["P"] - b["P"].double()).abs() / a["P"].abs().amax(dim=(1, 2), keepdim=True)).max()) <= 2e-4
+    # tiny batches against the first instances of the batch of five (shared noise model)
+    big = _make(cfg, ri, Q, R, sa, so, n, False, x0)
+    big.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])
+    ref = big.get_state()
+    for B in (1, 2, 3):
+        small = _make(cfg, ri, Q, R, sa, so, B, False, x0[:B])
+        small.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])
+        got = small.get_state()
+        for key in ("x", "P"):
+            assert torch.equal(got[key], ref[key][:B]), (B, key)
