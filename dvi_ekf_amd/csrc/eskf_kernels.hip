@@ -1067,8 +1067,10 @@ constexpr int R_C = 600;           // two 24-word column buffers (alternating)
 constexpr int R_J = 648;           // Jacobian record, blocks re-laid on even offsets (16-byte reads)
 constexpr int L_A = 0, L_TH = 10, L_BM = 20, L_CM = 30, L_DM = 48, L_EM = 60, L_DT = 70, L_N6 = 72;
 constexpr int R_RES = 744;         // residual of the update (7) + non-finite flag [+ the instance's noise record, 24 words]
-constexpr int R_REGION = 752;      // words per instance (even)
-constexpr int R_REGION_PIN = 776;  // with per-instance noise
+// words per instance: even, and = 24 (mod 32) -- with 24 lanes per instance consecutive instances of a block
+// then continue each other's bank pattern (row stride 25: lane t of the block hits bank 25 t mod 32)
+constexpr int R_REGION = 760;
+constexpr int R_REGION_PIN = 792;  // with per-instance noise
 __device__ __forceinline__ int lds_word(int e) {   // HBM record word -> LDS word
     return e + (e >= J_TH) + (e >= J_BM) + (e >= J_CM) + (e >= J_DT) + (e >= J_N6);
 }
@@ -1334,11 +1336,11 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 //   pos[lig][10]   image position (word offset i*25 + j) of the ten packed-record words lane lig moves
 //                  (pieces lig, lig+32, ... of 16 bytes; the last piece is clamped to the record's end)
 //   gat[row][24]   image position of P[row][j] in the lower-triangle image: max(row,j)*25 + min(row,j)
-struct RowsTables {
-    int pos[32][12];
+struct RowsTables {                  // [v]: lane layout v = 0: 32 lanes per instance, v = 1: 24 lanes per instance
+    int pos[2][32][16];
     int gat[24][24];
-    int jsrc[32][4];    // Jacobian record: the three record words lane lig moves (clamped to the record) ...
-    int jdst[32][4];    // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
+    int jsrc[2][32][4];  // Jacobian record: the record words lane lig moves (clamped to the record) ...
+    int jdst[2][32][4];  // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
 };
 constexpr int packed_image_pos(int e) {      // packed word e -> i*25 + j with i >= j (see unpack_ij)
     const int r = e / 25, c = e - 25 * r;
@@ -1346,20 +1348,23 @@ constexpr int packed_image_pos(int e) {      // packed word e -> i*25 + j with i
 }
 constexpr RowsTables make_rows_tables() {
     RowsTables t{};
-    for (int l = 0; l < 32; ++l)
-        for (int k = 0; k < 5; ++k) {
-            const int e2r = l + 32 * k, e2 = e2r < 150 ? e2r : 149;
-            t.pos[l][2 * k] = packed_image_pos(2 * e2);
-            t.pos[l][2 * k + 1] = packed_image_pos(2 * e2 + 1);
+    for (int v = 0; v < 2; ++v) {
+        const int lpi = v ? 24 : 32;
+        for (int l = 0; l < lpi; ++l) {
+            for (int k = 0; k < 8; ++k) {
+                const int e2r = l + lpi * k, e2 = e2r < 150 ? e2r : 149;
+                t.pos[v][l][2 * k] = packed_image_pos(2 * e2);
+                t.pos[v][l][2 * k + 1] = packed_image_pos(2 * e2 + 1);
+            }
+            for (int k = 0; k < 4; ++k) {
+                const int wr = l + lpi * k, w = wr < 88 ? wr : 87;
+                t.jsrc[v][l][k] = w;
+                t.jdst[v][l][k] = w + (w >= 9) + (w >= 18) + (w >= 27) + (w >= 66) + (w >= 67);
+            }
         }
+    }
     for (int r = 0; r < 24; ++r)
         for (int j = 0; j < 24; ++j) t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
-    for (int l = 0; l < 32; ++l)
-        for (int k = 0; k < 3; ++k) {
-            const int wr = l + 32 * k, w = wr < 88 ? wr : 87;
-            t.jsrc[l][k] = w;
-            t.jdst[l][k] = w + (w >= 9) + (w >= 18) + (w >= 27) + (w >= 66) + (w >= 67);
-        }
     return t;
 }
 __device__ const RowsTables kRowsTables = make_rows_tables();
@@ -1370,18 +1375,23 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 #endif
 // PIN: per-instance noise (diag(Q), diag(R) from the instance's noise record, staged into LDS with the
 // residual) instead of the parameter block
-template <typename T, bool PIN = false>
-__global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
+// LPI: lanes per instance.  32: one wavefront hosts two instances (8 of every 32 lanes idle, no barrier
+// needed: a block is one wave).  24: a block of three wavefronts hosts eight instances, every lane owns a
+// row; instances straddle wavefronts, so the exchanges are separated by real block barriers.
+template <typename T, bool PIN = false, int LPI = 32>
+__global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     using namespace rowk;
-    constexpr int LPI = 32, G = 2;
+    static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
+    constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
+    constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
     constexpr int REGION = PIN ? R_REGION_PIN : R_REGION;
     __shared__ __attribute__((aligned(16))) T smem[G * REGION];
 
     const int lane = threadIdx.x;
-    const int grp = lane >> 5;
-    const int lig = lane & 31;
-    const bool active = lig < 24;
-    const int row0 = active ? lig : 23;     // idle lanes shadow row 23 and write nothing
+    const int grp = LPI == 32 ? (lane >> 5) : (lane / 24);
+    const int lig = LPI == 32 ? (lane & 31) : (lane - 24 * grp);
+    const bool active = LPI == 24 || lig < 24;
+    const int row0 = active ? lig : 23;     // (32-lane layout: idle lanes shadow row 23 and write nothing)
 
     T* sB = smem + grp * REGION + R_BUF;
     T* sC = smem + grp * REGION + R_C;
@@ -1391,7 +1401,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     // last word of the record in use (dt without the gyro block of Q, else the end of N6) and its LDS slot
     const int jlast = prm.q_gyro ? J_FULL - 1 : J_CORE - 1;
     const int jlast_lds = prm.q_gyro ? L_N6 + 17 : L_DT;
-    constexpr int NJ = (J_FULL + LPI - 1) / LPI;
+    constexpr int NJ = (JW + LPI - 1) / LPI;
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
 
@@ -1422,27 +1432,26 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         asm volatile("" : "+v"(lj_));   /* (per-lane addresses formed here, not kept across rounds) */ \
         const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
         _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w_ = kRowsTables.jsrc[lj_][k];                                               \
+            const int w_ = kRowsTables.jsrc[TV][lj_][k];                                           \
             DST[k] = gJ_[w_ < jlast ? w_ : jlast];   /* (the padding of the record is not fetched) */ \
         }                                                                                          \
-        if (PIN && lj_ >= 8)                                                                       \
-            RES = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + lj_ - 8];    \
-        else                                                                                       \
-            RES = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];              \
+        RES.x = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                \
+        if (PIN) RES.y = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + (lj_ < 24 ? lj_ : 23)]; \
     }
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
         _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w_ = kRowsTables.jdst[lig][k];                                               \
+            const int w_ = kRowsTables.jdst[TV][lig][k];                                           \
             sJ[w_ < jlast_lds ? w_ : jlast_lds] = SRC[k];                                          \
         }                                                                                          \
-        sR[PIN ? lig : (lig & 7)] = RES;                                                           \
+        sR[lig & 7] = RES.x;            /* (several lanes, same value) */                          \
+        if (PIN) sR[8 + (lig < 24 ? lig : 23)] = RES.y;                                            \
     }
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
         int off_[2 * NV], gat_[24];                                                                \
-        _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = kRowsTables.pos[lig][k];      \
+        _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = kRowsTables.pos[TV][lig][k];      \
         _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gat[row][j];          \
         _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
             sB[off_[2 * k]] = pv[k].x;                                                             \
@@ -1467,7 +1476,9 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     asm volatile("" : "+v"(row), "+v"(inst));
     {   // packed covariance into registers, first Jacobian record and residual into LDS
         ESKF_ISSUE_LOADS(inst)
-        T j0[NJ], r0 = T(0);
+        T j0[NJ];
+        T2 r0;
+        r0.x = r0.y = T(0);
         ESKF_LOAD_J(j0, r0, inst, 0)
         ESKF_STAGE_J(j0, r0)
     }
@@ -1479,7 +1490,9 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
     // ================================ predict(s) =======================================
     for (int ip = 0; ip < a.n_pred; ++ip) {
         if (ip > 0) {                       // (the first record was staged at the end of the previous round)
-            T jn[NJ], rn = T(0);
+            T jn[NJ];
+            T2 rn;
+            rn.x = rn.y = T(0);
             ESKF_LOAD_J(jn, rn, inst, ip)
             ESKF_STAGE_J(jn, rn)
             group_sync();
@@ -1625,7 +1638,7 @@ __global__ __launch_bounds__(64, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs 
         T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
         int off[2 * NV];
 #pragma unroll
-        for (int k = 0; k < 2 * NV; ++k) off[k] = kRowsTables.pos[lig][k];
+        for (int k = 0; k < 2 * NV; ++k) off[k] = kRowsTables.pos[TV][lig][k];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e2 = lig + k * LPI;
@@ -1851,12 +1864,12 @@ static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipSt
     return hipGetLastError();
 }
 
-template <typename T, bool PIN = false>
+template <typename T, bool PIN = false, int LPI = 32>
 static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
-    constexpr int G = 2;
+    constexpr int G = LPI == 32 ? 2 : 8;                    // instances per block
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
-    const int64_t blocks = (a.B + G - 1) / G;               // one wavefront per two instances
-    hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+    const int64_t blocks = (a.B + G - 1) / G;
+    hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, LPI>), dim3((unsigned)blocks), dim3(LPI == 32 ? 64 : 192), 0, stream, a, prm);
     return hipGetLastError();
 }
 
@@ -1870,9 +1883,14 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (e != hipSuccess) return e;
     // 2. covariance.  With per-instance noise: the PIN variants (row-resident, or the LDS-image kernel
     // with 32 lanes per instance when the gain matrix is asked for or that kernel is selected)
-    if (a.noise)
-        return (lpi == 1 && !a.K_out) ? launch_cov_rows<T, true>(a, prm, stream) : launch_cov_t<T, 32, true>(a, prm, stream);
+    if (a.noise) {
+        if (a.K_out || (lpi != 1 && lpi != 2)) return launch_cov_t<T, 32, true>(a, prm, stream);
+        return lpi == 2 ? launch_cov_rows<T, true, 24>(a, prm, stream) : launch_cov_rows<T, true, 32>(a, prm, stream);
+    }
     switch (lpi) {
+        case 2:  // DVI_ESKF_LANES_ROWS24
+            e = a.K_out ? launch_cov_t<T, 32>(a, prm, stream) : launch_cov_rows<T, false, 24>(a, prm, stream);
+            break;
         case 1:  // DVI_ESKF_LANES_ROWS; the gain matrix is only formed by the LDS-image kernel
             e = a.K_out ? launch_cov_t<T, 32>(a, prm, stream) : launch_cov_rows<T>(a, prm, stream);
             break;

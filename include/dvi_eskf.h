@@ -172,6 +172,7 @@ int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int
  * 64 / 32 / 24 / 16 / 12 / 8: LDS-image kernel with that many lanes per instance (64 = one
  * wavefront per instance).  All variants compute the same step; they differ in rounding only. */
 #define DVI_ESKF_LANES_ROWS 1
+#define DVI_ESKF_LANES_ROWS24 2   /* row-resident kernel, 24 lanes per instance: eight instances per block of three wavefronts */
 int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes);
 
 const char* dvi_eskf_strerror(int code);

@@ -255,6 +255,29 @@ def test_lane_layout_variants_agree(lpi):
         assert torch.equal(a[key], b[key]), key
 
 
+@pytest.mark.parametrize("B", [1, 8, 23])
+def test_row_resident_lane_layouts_are_bitwise_identical(B):
+    """Selector 2 = the row-resident kernel with 24 lanes per instance (eight instances per block of three
+    wavefronts, block barriers between the exchanges) against selector 1 (32 lanes per instance, one
+    wavefront per two instances): the same arithmetic per lane."""
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    x0 = _perturbed_x0(ri, B)
+    fa = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=1)
+    fb = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=2)
+    ip = 0
+    for k in range(3):
+        for _ in range(ri.n_pred[k]):
+            fa.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            fb.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            ip += 1
+        sta, _ = fa.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        stb, _ = fb.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        assert torch.equal(sta, stb)
+        a, b = fa.get_state(), fb.get_state()
+        for key in a:
+            assert torch.equal(a[key], b[key]), (k, key)
+
+
 @pytest.mark.parametrize("tune", [False, True])
 def test_row_resident_kernel_matches_lds_image_kernel(tune):
     """The two covariance kernels (rows of P in registers / full image in LDS) are the same
