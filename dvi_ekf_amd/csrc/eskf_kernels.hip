@@ -1061,7 +1061,7 @@ __device__ __forceinline__ float fast_rcp(float x) {
 
 namespace rowk {
 // exchange image: row stride PS = 25 (conflict-free row writes and column reads)
-constexpr int XS = 10;             // row stride of the [24][6] panel of the reset (16-byte rows, <= 2-way conflicts)
+constexpr int XS = 9;              // row stride of the [24][6] panel of the reset (odd: conflict-free 8-byte accesses)
 constexpr int R_BUF = 0;           // 24 x 25 exchange image | [24][XS] panel of the reset
 constexpr int R_C = 600;           // two 24-word column buffers (alternating)
 constexpr int R_J = 648;           // Jacobian record, blocks re-laid on even offsets (16-byte reads)
