@@ -1354,6 +1354,7 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 struct RowsTables {                  // [v]: lane layout v = 0: 32 lanes per instance, v = 1: 24 lanes per instance
     int pos[2][32][16];
     int gat[24][24];
+    int gatp[24][24];    // packed-record word of P[row][j] (= of P[max][min])
     int jsrc[2][32][4];  // Jacobian record: the record words lane lig moves (clamped to the record) ...
     int jdst[2][32][4];  // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
 };
@@ -1379,7 +1380,11 @@ constexpr RowsTables make_rows_tables() {
         }
     }
     for (int r = 0; r < 24; ++r)
-        for (int j = 0; j < 24; ++j) t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
+        for (int j = 0; j < 24; ++j) {
+            t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
+            const int hi = j <= r ? r : j, lo = j <= r ? j : r;
+            t.gatp[r][j] = hi < 12 ? (25 * hi + lo) : (25 * (23 - hi) + (23 - hi) + 1 + lo);
+        }
     return t;
 }
 __device__ const RowsTables kRowsTables = make_rows_tables();
@@ -1427,17 +1432,6 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
     // formed where they are used instead of being kept in registers from the prologue on.
     const int nB = (int)a.B;
     const int slot = (int)blockIdx.x * G + grp;
-    T2 pv[NV];
-#define ESKF_ISSUE_LOADS(INST)                                                                     \
-    {   /* (no predicates: the last piece is fetched twice by the lanes beyond the record) */       \
-        int lp_ = lig;                                                                             \
-        asm volatile("" : "+v"(lp_));                                                              \
-        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P) + (int64_t)(INST) * 300); \
-        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
-            const int e2 = lp_ + k * LPI;                                                          \
-            pv[k] = gP2_[e2 < 150 ? e2 : 149];                                                     \
-        }                                                                                          \
-    }
     // Jacobian record IP of instance INST and the residual of the update -> registers -> LDS.  No
     // predicates either: every lane moves three record words (the 88-word record is padded; what
     // lies beyond the blocks in use lands in the idle N6 area) and one residual word.
@@ -1463,18 +1457,15 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
         if (PIN) sR[8 + (lig < 24 ? lig : 23)] = RES.y;                                            \
     }
     // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
+    // row `row` of P straight from the packed record: 24 eight-byte loads per lane with per-lane addresses
+    // (the record's 38 cache lines are touched once and then hit in L1); no LDS involved
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
-        int off_[2 * NV], gat_[24];                                                                \
-        _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = kRowsTables.pos[TV][lig][k];      \
-        _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gat[row][j];          \
-        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
-            sB[off_[2 * k]] = pv[k].x;                                                             \
-            sB[off_[2 * k + 1]] = pv[k].y;                                                         \
-        }                                                                                          \
-        group_sync();                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[gat_[j]];                         \
-        group_sync();                                                                              \
+        const T* gP_ = reinterpret_cast<const T*>(a.P) + (int64_t)inst * 300;                      \
+        int gat_[24];                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gatp[row][j];         \
+        _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = gP_[gat_[j]];                        \
+        group_sync();   /* (the staged Jacobian record and residual are visible to every lane) */    \
     }
     // one predict on the row-resident P with the Jacobian record that sits in LDS
 #define ESKF_PREDICT_ROWS()                                                                        \
@@ -1490,7 +1481,6 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
     int row = row0;
     asm volatile("" : "+v"(row), "+v"(inst));
     {   // packed covariance into registers, first Jacobian record and residual into LDS
-        ESKF_ISSUE_LOADS(inst)
         T j0[NJ];
         T2 r0;
         r0.x = r0.y = T(0);
@@ -1665,7 +1655,6 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
             }
         }
     }
-#undef ESKF_ISSUE_LOADS
 #undef ESKF_LOAD_J
 #undef ESKF_STAGE_J
 #undef ESKF_UNPACK_ROW
