@@ -152,3 +152,43 @@ def test_config4_monte_carlo_driver_single_gpu():
     assert np.abs(np.array(a["reference_instance_dofs"]) - o.x[0, 10:16]).max() <= 1e-9
     c = run_monte_carlo(4096, frames=6, seed=5)
     assert c["dof_mse_mean"] != a["dof_mse_mean"]
+
+
+def test_random_covariances_row_resident_vs_lds_image_vs_oracle():
+    """4096 instances with random SPD covariances (not reachable from the filter's own history) through one
+    predict+update pair: the two covariance kernels -- measurement-by-measurement update on rows in
+    registers vs explicit LDL^T on an LDS image -- agree to rounding x conditioning, and a subset agrees
+    with the C oracle's explicit-inverse gain."""
+    from oracle import c_oracle
+    from tests.test_gpu_parity import _make, _perturbed_x0, _rel
+    B = 4096
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    rng = np.random.default_rng(123)
+    x0 = _perturbed_x0(ri, B)
+    A = rng.standard_normal((B, 24, 24))
+    scale = 10.0 ** rng.uniform(-3, 0, (B, 24, 1))              # rows of very different size
+    A = A * scale
+    P0 = A @ A.transpose(0, 2, 1) / 24 + 1e-6 * np.eye(24)
+    fa = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=1)
+    fb = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=32)
+    for f in (fa, fb):
+        f.set_state(P=P0)
+        f.predict(ri.dt[0], ri.om[0], ri.acc[0])
+        st, _ = f.update(ri.pos[0], ri.quat[0], ri.notch[0])
+        assert int(st.max()) == 0
+    a, b = fa.get_state(), fb.get_state()
+    for key, tol in (("x", 1e-9), ("P", 1e-9)):
+        s = a[key].abs().amax(dim=tuple(range(1, a[key].dim())), keepdim=True)
+        d = float(((a[key] - b[key]).abs() / s).max())
+        print(f"random SPD, rows vs LDS image: {key} max rel {d:.2e}")
+        assert d <= tol, key
+    n = 64
+    prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, False, sa, so, Q, R)
+    o = c_oracle.OracleBatch(prm, x0[:n], ri.P0, ri.om0, ri.acc0)
+    o.P[:] = P0[:n]
+    o.predict(ri.dt[0], ri.om[0], ri.acc[0])
+    o.update(ri.pos[0], ri.quat[0], ri.notch[0])
+    ex = max(_rel(a["x"][i].cpu().numpy(), o.x[i], 1) for i in range(n))
+    eP = max(_rel(a["P"][i].cpu().numpy(), o.P[i], 1) for i in range(n))
+    print(f"random SPD, rows vs oracle: x {ex:.2e} P {eP:.2e}")
+    assert ex <= 1e-8 and eP <= 1e-8
