@@ -65,6 +65,27 @@ def cpu_baseline(wl, seconds_target=12.0):
                       f"same workload, {t:.1f} s"}
 
 
+def cpu_baseline_numpy(wl, steps=16):
+    """the NumPy twin of the reference's arithmetic (oracle/eskf_ref.py, complex-step
+    Jacobians), ONE instance on ONE core -- the closest analogue of the reference's own CasADi/NumPy path;
+    optimistic, since the reference also rebuilds its symbolic graph every step."""
+    from oracle.eskf_ref import RefFilter, RefParams
+    prm = RefParams(L=wl.cfg.model.length, theta_cam=wl.cfg.model.angle, frozen=tuple(wl.cfg.frozen_dofs), hold_frozen=True,
+                    sigma_a=np.asarray(wl.sigma_a, dtype=float), sigma_om=np.asarray(wl.sigma_om, dtype=float),
+                    Q=np.asarray(wl.Q, dtype=float), R=np.asarray(wl.R, dtype=float))
+    f = RefFilter(prm, wl.x0[0].cpu().numpy(), wl.P0.cpu().numpy(), wl.om0.cpu().numpy(), wl.acc0.cpu().numpy())
+    n = min(steps, wl.horizon)
+    host = [(float(wl.dt[k, 0]), wl.om[k, 0].cpu().numpy(), wl.acc[k, 0].cpu().numpy(), wl.pos[k, 0].cpu().numpy(),
+             wl.quat[k, 0].cpu().numpy(), float(wl.notch[k, 0])) for k in range(n)]
+    t0 = time.perf_counter()
+    for dt, om, acc, pos, quat, notch in host:
+        f.predict(dt, om, acc)
+        f.update(pos, quat, notch)
+    t = time.perf_counter() - t0
+    return {"value": n / t, "unit": "pair-steps/s", "cores": 1, "kind": "port",
+            "sample": f"NumPy twin (oracle/eskf_ref.py), instance 0 x {n} pair-steps, {t:.2f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +281,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
+            out["cpu_baseline_numpy"] = cpu_baseline_numpy(wl)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
