@@ -20,7 +20,7 @@ def _population(Q, R, so, n, rng, gyro):
     return q, r, s
 
 
-@pytest.mark.parametrize("gyro,lpi", [(False, 1), (True, 1), (False, 32), (True, 32)])
+@pytest.mark.parametrize("gyro,lpi", [(False, 1), (True, 1), (False, 2), (True, 2), (False, 32), (True, 32)])
 def test_population_equals_one_filter_per_candidate(gyro, lpi):
     """lpi = 1: row-resident kernel (noise record staged into LDS), 32: LDS-image kernel; the single-model
     filters run the same kernel with the noise in the parameter block."""
