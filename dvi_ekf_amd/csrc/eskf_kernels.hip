@@ -1173,7 +1173,6 @@ __device__ __forceinline__ void fx_apply_store(const T* sJ, const T (&v)[24], T*
             lds_store1(dst + 17, v[17]);
         }
     }
-    asm volatile("" : : : "memory");
     {
         T o[3];
 #pragma unroll
@@ -1195,7 +1194,6 @@ __device__ __forceinline__ void fx_apply_store(const T* sJ, const T (&v)[24], T*
             for (int r = 0; r < 3; ++r) lds_store1(dst + 18 + r, o[r]);
         }
     }
-    asm volatile("" : : : "memory");
     {
         T o[3];
 #pragma unroll
@@ -1248,7 +1246,6 @@ __device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[2
             u[r] = x;
         }
     }
-    asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]) : : "memory");
     {   // inputs 9..17
         T c[9];
 #pragma unroll
@@ -1275,7 +1272,6 @@ __device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[2
             w[r] = y;
         }
     }
-    asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(w[0]), "+v"(w[1]), "+v"(w[2]) : : "memory");
     {   // inputs 18..23
         T c[6];
 #pragma unroll
