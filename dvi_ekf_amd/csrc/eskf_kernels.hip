@@ -1452,16 +1452,37 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
         sR[lig & 7] = RES.x;            /* (several lanes, same value) */                          \
         if (PIN) sR[8 + (lig < 24 ? lig : 23)] = RES.y;                                            \
     }
-    // packed covariance (registers pv) -> lower-triangle image -> row `row` in registers
-    // row `row` of P straight from the packed record: 24 eight-byte loads per lane with per-lane addresses
-    // (the record's 38 cache lines are touched once and then hit in L1); no LDS involved
+    // row `row` of P from the packed record.  fp64: 24 eight-byte loads per lane with per-lane addresses (the
+    // record's 38 cache lines are touched once and then hit in L1; no LDS involved).  fp32: the four-byte
+    // version of that is texture-addresser bound (measured 18 % slower on the 1M-instance predict-only
+    // configuration), so the record is fetched in 16-byte pieces, scattered into the lower-triangle LDS
+    // image and gathered from there.
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
         const T* gP_ = reinterpret_cast<const T*>(a.P) + (int64_t)inst * 300;                      \
-        int gat_[24];                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gatp[row][j];         \
-        _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = gP_[gat_[j]];                        \
-        group_sync();   /* (the staged Jacobian record and residual are visible to every lane) */    \
+        if (sizeof(T) == 8) {                                                                      \
+            int gat_[24];                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gatp[row][j];     \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = gP_[gat_[j]];                    \
+            group_sync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
+        } else {                                                                                   \
+            const T2* gP2_ = reinterpret_cast<const T2*>(gP_);                                     \
+            T2 pv_[NV];                                                                            \
+            int off_[2 * NV], gat_[24];                                                            \
+            _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                       \
+                const int e2 = lig + k * LPI;                                                      \
+                pv_[k] = gP2_[e2 < 150 ? e2 : 149];                                                \
+            }                                                                                      \
+            _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = kRowsTables.pos[TV][lig][k]; \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gat[row][j];      \
+            _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                       \
+                sB[off_[2 * k]] = pv_[k].x;                                                        \
+                sB[off_[2 * k + 1]] = pv_[k].y;                                                    \
+            }                                                                                      \
+            group_sync();                                                                          \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[gat_[j]];                     \
+            group_sync();                                                                          \
+        }                                                                                          \
     }
     // one predict on the row-resident P with the Jacobian record that sits in LDS
 #define ESKF_PREDICT_ROWS()                                                                        \

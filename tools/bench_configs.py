@@ -66,8 +66,38 @@ def epoch10(B=65536, N=10):
             "frac_of_8TBps": B * bytes_per / t / 8e12, "state_restore_every": 4}
 
 
+def config5(B=8192, frames=64):
+    """Config #5 shape: 1 kHz IMU / 30 Hz vision, fp32 -- one launch per camera frame = 33/33/34 predicts
+    (dt = 1e-3) + 1 update, P resident on chip across the predicts.  Synthetic IMU samples (throughput only)."""
+    from dvi_ekf_amd.workloads import monte_carlo_pairs
+    dev = torch.device("cuda:0")
+    wl = monte_carlo_pairs(B, horizon=4, seed=5, device=dev)
+    f = wl.make_filter(dtype=torch.float32)
+    snap = f.clone()
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    counts = [33, 33, 34]
+    dts = [torch.full((n,), 1e-3, device=dev, dtype=torch.float32) for n in counts]
+    oms = [0.05 * torch.randn((n, 3), generator=g, device=dev, dtype=torch.float32) for n in counts]
+    accs = [1.0 * torch.randn((n, 3), generator=g, device=dev, dtype=torch.float32) for n in counts]
+    pos, quat, notch = wl.pos[0].float(), wl.quat[0].float(), wl.notch[0].float()
+    k = [0]
+
+    def frame():
+        if k[0] % 8 == 0:
+            f.copy_state_from(snap)
+        i = k[0] % 3
+        f.epoch(dts[i], oms[i], accs[i], pos, quat, notch)
+        k[0] += 1
+
+    t = _time(frame, frames, warm=6)
+    steps_per_frame = 100.0 / 3
+    return {"config": "#5 shape: 1 kHz IMU / 30 Hz vision, fp32, one launch per frame", "batch": B, "ms_per_frame": t * 1e3,
+            "imu_steps_per_s": B * steps_per_frame / t, "frames_per_s": B / t, "unit": "instance-steps/s",
+            "finite": bool(torch.isfinite(f.x).all())}
+
+
 if __name__ == "__main__":
-    what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["config3", "epoch10"]
+    what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["config3", "epoch10", "config5"]
     B3 = 1048576
     if "--batch3" in sys.argv:
         B3 = int(sys.argv[sys.argv.index("--batch3") + 1])
@@ -75,3 +105,5 @@ if __name__ == "__main__":
         print(json.dumps(config3(B3)))
     if "epoch10" in what:
         print(json.dumps(epoch10()))
+    if "config5" in what:
+        print(json.dumps(config5()))
