@@ -72,15 +72,18 @@ class VisualTraj:
             setattr(self, c, None if table is None else np.asarray(table[c], dtype=float))
         self.quats: List[Quaternion] = []
         self.notch = self.notch_d = self.notch_dd = None
+        self.with_notch = False
+        self.is_rotated = False
         self.v = self.acc = self.om = self.alp = None
         if table is not None:
             self.gen_angle_arrays()
 
     @classmethod
     def from_csv(cls, name: str, filepath, cap: Optional[int] = None, scale: Optional[float] = None,
-                 start_at: Optional[float] = None) -> "VisualTraj":
+                 start_at: Optional[float] = None, notch_filepath=None, with_notch: bool = False) -> "VisualTraj":
         """files.get_dataframe (files.py:19-28) + _filter_values + _scale_values
-        (VisualTrajectory.py:76-108)."""
+        (VisualTrajectory.py:76-108); with ``with_notch`` also the notch columns
+        (VisualTrajectory.py:66-70)."""
         filepath = str(filepath)
         if not filepath.endswith(".csv"):
             raise ValueError("camera trajectory must be a .csv file")
@@ -91,13 +94,43 @@ class VisualTraj:
             rows = rows[:cap]
         data = np.array(rows, dtype=float)
         table = {h: data[:, header.index(h)] for h in _COLS}
+        i0 = 0
         if start_at:
             i0 = int(np.argwhere(table["t"] == start_at).item())
             table = {k: v[i0:(i0 + cap if cap else None)] for k, v in table.items()}
         if scale:
             for k in ("x", "y", "z"):
                 table[k] = table[k] * scale
-        return cls(name, table)
+        traj = cls(name, table)
+        if with_notch:
+            traj.read_notch_from_file(notch_filepath, start_index=i0, cap=cap)
+        return traj
+
+    def read_notch_from_file(self, notch_filepath, start_index: int = 0, cap: Optional[int] = None) -> None:
+        """One line per camera frame: notch angle [rad], its rate and its acceleration.
+
+        This is what VisualTrajectory.read_notch_from_file (110-118) is written to do; as
+        shipped in v1 it cannot run (it whitespace-splits the comma-separated ``notch*.csv``
+        and appends to attributes that are still ``None``), so there is no reference output
+        to match -- the columns are taken as the file gives them, for either separator, and
+        cut to the same frame window as the pose columns (VisualTrajectory.py:69-70)."""
+        if notch_filepath is None:
+            raise ValueError("camera.with_notch needs a notch trajectory file")
+        rows = []
+        with open(str(notch_filepath)) as f:
+            for ln in f:
+                parts = ln.replace(",", " ").split()
+                if parts:
+                    if len(parts) < 3:
+                        raise ValueError(f"{notch_filepath}: expected 3 columns per line, got {len(parts)}")
+                    rows.append([float(v) for v in parts[:3]])
+        data = np.asarray(rows, dtype=float).reshape(-1, 3)
+        stop = start_index + cap if cap else (start_index + len(self.t) if start_index else None)
+        data = data[start_index:stop]
+        if len(data) != len(self.t):
+            raise ValueError(f"{notch_filepath}: {len(data)} notch samples for {len(self.t)} camera frames")
+        self.notch, self.notch_d, self.notch_dd = data[:, 0].copy(), data[:, 1].copy(), data[:, 2].copy()
+        self.with_notch = True
 
     def gen_angle_arrays(self) -> None:
         """Per-frame unit quaternions (VisualTrajectory.py:136-149)."""
@@ -120,13 +153,10 @@ class Camera:
     def __init__(self, filepath=None, notch_filepath=None, traj: Optional[VisualTraj] = None,
                  max_vals: Optional[int] = None, scale: Optional[float] = None, with_notch: bool = False,
                  start_at=None, euler_rate: str = "xyz"):
-        if with_notch:
-            # the reference's notch reader is broken in v1 (VisualTrajectory.py:110-118
-            # whitespace-splits a comma-separated file); SURVEY.md 8(f) item 4
-            raise NotImplementedError("camera.with_notch is not supported (broken in the reference v1)")
         self.euler_rate = euler_rate
         self.traj = traj if traj is not None else VisualTraj.from_csv(
-            "camera", filepath, cap=max_vals, scale=scale, start_at=start_at)
+            "camera", filepath, cap=max_vals, scale=scale, start_at=start_at, notch_filepath=notch_filepath,
+            with_notch=with_notch)
         self.max_vals = len(self.traj.t)
         self.t = self.traj.t
         self.dt = float(self.t[1] - self.t[0])
@@ -157,9 +187,18 @@ class Camera:
         self.p0 = self.p[:, 0].copy().reshape(3, 1)
         self.q0 = Quaternion(val=self.q[:, 0].copy(), do_normalise=True)
         self.vec0 = self.vec_at(0)
-        self.with_notch = False
-        self.rotated = None
+        # notch (Camera.py:120-137)
+        self.with_notch = bool(with_notch)
+        self.is_rotated = False
+        self.rotated: Optional["Camera"] = None
         self.notch = self.notch_d = self.notch_dd = None
+        if self.flag_interpolated and self.traj.with_notch:
+            self.notch, self.notch_d, self.notch_dd = self.traj.notch, self.traj.notch_d, self.traj.notch_dd
+        if with_notch:
+            if self.traj.notch is None:
+                raise ValueError("with_notch: the trajectory carries no notch columns")
+            self.notch, self.notch_d, self.notch_dd = self.traj.notch, self.traj.notch_d, self.traj.notch_dd
+            self.gen_rotated()
 
     @property
     def flag_interpolated(self) -> bool:
@@ -185,11 +224,72 @@ class Camera:
         for lab in ("v", "acc", "om", "alp"):
             src = getattr(self, lab)
             setattr(out, lab, np.asarray([np.interp(t_new, t_old, src[i]) for i in range(3)]))
+        if self.with_notch:                                  # Interpolator.py:48-52,82-88
+            for lab in ("notch", "notch_d", "notch_dd"):
+                setattr(out, lab, np.interp(t_new, t_old, getattr(self, lab)))
+            out.with_notch = True
         out.interframe_vals = interframe_vals
         out.is_interpolated = True
-        return Camera(traj=out, euler_rate=self.euler_rate)
+        cam = Camera(traj=out, euler_rate=self.euler_rate)
+        cam.with_notch = self.with_notch                     # Camera.py:154-155
+        return cam
+
+    def gen_rotated(self) -> None:
+        """The camera as the probe's notch joint turns it: every orientation is
+        pre-multiplied by a rotation about z by the notch angle (Camera.py:172-202).
+        Positions are shared; rates are re-derived from the rotated poses."""
+        table = {c: np.array(getattr(self.traj, c), dtype=float, copy=True) for c in _COLS}
+        rotated_quats = []
+        for i in range(len(self.t)):
+            notch_quat = Quaternion(val=np.array([0.0, 0.0, self.get_notch_vec_at(i)[0]]), euler="xyz")
+            rotated_quats.append(notch_quat * self.traj.quats[i])
+        for j, c in enumerate(("qx", "qy", "qz", "qw")):
+            table[c] = np.array([q.xyzw[j] for q in rotated_quats])
+        rotated_traj = VisualTraj("camera rot", table)
+        rotated_traj.quats = rotated_quats                   # the products themselves, not re-normalised copies
+        rotated_traj.is_rotated = True
+        self.rotated = Camera(filepath=None, traj=rotated_traj, euler_rate=self.euler_rate)
+        self.rotated.is_rotated = True
+        self.rotated.with_notch = self.with_notch
+        self.rotated.notch, self.rotated.notch_d, self.rotated.notch_dd = self.notch, self.notch_d, self.notch_dd
+
+    def generate_notch_values(self, ang_fractions=(0, 0, 0.9, 0.9, -0.45, -0.45),
+                              partitions=(0, 0.1, 0.45, 0.5, 0.9, 1)) -> np.ndarray:
+        """Piecewise septic smooth-step notch trajectory over the camera's time base
+        (Camera._gen_notch_values / _gen_t_partition, Camera.py:209-274): the angle
+        rests at pi*ang_fractions[k] at the partition boundaries and moves between them
+        with zero rate, acceleration and jerk at both ends.  Returns [n,3] = angle, rate,
+        acceleration and installs the columns (then ``gen_rotated()`` is up to date)."""
+        ang_vals = np.pi * np.asarray(ang_fractions, dtype=float)
+        bounds = [int(np.ceil(p * self.max_vals)) for p in partitions]
+        cols = [[], [], []]
+        ang_prev, t_prev = ang_vals[0], float(self.t[0])
+        for k, ang_k in enumerate(ang_vals[1:]):
+            t_seg = np.asarray(self.t[bounds[k]:bounds[k + 1]], dtype=float)
+            t_end = float(t_seg[-1])
+            tau, T = t_seg - t_prev, t_end - t_prev
+            d = ang_k - ang_prev
+            if T == 0.0:                                      # a one-sample first segment at rest
+                z, zd, zdd = ang_prev + 0 * tau, 0 * tau, 0 * tau
+            else:
+                z = ang_prev + d * (35 * (tau / T) ** 4 - 84 * (tau / T) ** 5 + 70 * (tau / T) ** 6 - 20 * (tau / T) ** 7)
+                zd = d * (35 * 4 / T ** 4 * tau ** 3 - 84 * 5 / T ** 5 * tau ** 4
+                          + 70 * 6 / T ** 6 * tau ** 5 - 20 * 7 / T ** 7 * tau ** 6)
+                zdd = d * (35 * 4 * 3 / T ** 4 * tau ** 2 - 84 * 5 * 4 / T ** 5 * tau ** 3
+                           + 70 * 6 * 5 / T ** 6 * tau ** 4 - 20 * 7 * 6 / T ** 7 * tau ** 5)
+            for c, v in zip(cols, (z, zd, zdd)):
+                c.append(v)
+            t_prev, ang_prev = t_end, ang_k
+        self.notch, self.notch_d, self.notch_dd = (np.concatenate(c).ravel() for c in cols)
+        self.traj.notch, self.traj.notch_d, self.traj.notch_dd = self.notch, self.notch_d, self.notch_dd
+        self.traj.with_notch = self.with_notch = True
+        self.gen_rotated()
+        return np.stack([self.notch, self.notch_d, self.notch_dd], axis=1)
 
     def get_notch_vec_at(self, i: int) -> np.ndarray:
+        """Camera.py:276-280."""
+        if self.with_notch:
+            return np.array([self.notch[i], self.notch_d[i], self.notch_dd[i]])
         return np.array([0.0, 0.0, 0.0])
 
     def vec_at(self, i: int) -> List[np.ndarray]:
@@ -202,9 +302,14 @@ class Camera:
         Camera.py:320-347)."""
         old_i = max(i for i, t in enumerate(self.t) if t <= old_t)
         new_i = max(i for i, t in enumerate(self.t) if t <= new_t)
+        def notch_at(i):
+            if self.with_notch:
+                return float(self.notch[i]), float(self.notch_d[i]), float(self.notch_dd[i])
+            return 0.0, 0.0, 0.0
+
         return [
             CameraMeasurementPoint(self.t[i], self.p[:, i], self.R[i], self.v[:, i], self.om[:, i],
-                                   self.acc[:, i], self.alp[:, i], 0.0, 0.0, 0.0)
+                                   self.acc[:, i], self.alp[:, i], *notch_at(i))
             for i in range(old_i + 1, new_i + 1)
         ]
 
@@ -220,5 +325,6 @@ def create_camera(config) -> Camera:
         start_at=config.camera.start_frame,
         euler_rate="XYZ" if getattr(config, "golden_compat", False) else "xyz",
     )
+    assert (cam.rotated is not None) == bool(config.with_notch)
     cam.update_sim_params(config)
     return cam

@@ -138,7 +138,8 @@ class Imu:
     def create(config, camera, probe, gen_ref: bool = False) -> "Imu":
         """Imu.create (Imu.py:87-97): ``config`` is the ImuConfig in the reference;
         any object with interframe_vals/stdev_accel/stdev_omega works."""
-        return Imu(probe, camera.interpolate(config.interframe_vals), config.stdev_accel,
+        cam_reference = camera.rotated if camera.rotated else camera   # Imu.py:89: the IMU rides the rotated camera
+        return Imu(probe, cam_reference.interpolate(config.interframe_vals), config.stdev_accel,
                    config.stdev_omega, gen_ref=gen_ref)
 
     def reset(self) -> None:

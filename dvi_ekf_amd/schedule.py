@@ -41,11 +41,12 @@ class RunInputs:
 def initial_state(camera, imu, dofs_ic) -> np.ndarray:
     """get_ic (utils.py:54-75): IMU pose from the first camera frame through the
     real probe; the YAML ``filter.ic.x0`` block is not used by the reference."""
-    notch0 = camera.get_notch_vec_at(0)
-    p_B, R_WB, v_B = imu.ref_vals(camera.vec0, notch0)
+    cam_reference = camera.rotated if camera.rotated else camera       # utils.py:63
+    notch0 = cam_reference.get_notch_vec_at(0)
+    p_B, R_WB, v_B = imu.ref_vals(cam_reference.vec0, notch0)
     q = Quaternion(val=R_WB, do_normalise=True)
     return np.concatenate([p_B, v_B, q.xyzw, np.asarray(dofs_ic, dtype=float), notch0,
-                           camera.p0.reshape(3), camera.q0.xyzw])
+                           cam_reference.p0.reshape(3), cam_reference.q0.xyzw])
 
 
 def build_run_inputs(config, camera, imu, probe) -> RunInputs:

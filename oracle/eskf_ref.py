@@ -205,6 +205,7 @@ class RefFilter:
         self.Fx = None
         self.Fi = None
         self.K = None
+        self.res = None
         H = np.zeros((NM, NE))
         H[0:6, 18:24] = np.eye(6)
         H[6, 15] = 1
@@ -358,6 +359,7 @@ class RefFilter:
         res_q = quat_angle_axis_residual(err_q)
         res_n = ang_notch - self.x[16]
         res = np.hstack((res_p, res_q, res_n))
+        self.res = res
 
         e = K @ res
         for i, fr in enumerate(prm.frozen):                                            # Filter.py:377-379

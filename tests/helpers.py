@@ -19,11 +19,13 @@ KF_BEST = os.path.join(GOLDEN, "data", "trajs", "kf_best_mandala0_mono.txt")
 IMU_REF = os.path.join(GOLDEN, "data", "trajs", "imu_ref_mandala0_mono.txt")
 
 
-def default_run(golden_compat: bool = True, fast: bool = True, frozen=None, interframe=None):
+def default_run(golden_compat: bool = True, fast: bool = True, frozen=None, interframe=None, with_notch: bool = False,
+                max_vals=None):
     """Returns (cfg, run_inputs, Q, R, sigma_a, sigma_om).
 
     golden_compat=True  -> plumbing G1/G2/G3 of SURVEY.md 8(c) (what the saved file needs)
-    fast=False          -> all 140 frames instead of the fast-sim 10"""
+    fast=False          -> all 140 frames instead of the fast-sim 10
+    with_notch=True     -> camera.with_notch: the notch90 trajectory turns the camera"""
     cfg = Config(os.path.join(GOLDEN, "config.yaml"), base_dir=GOLDEN)
     cfg.golden_compat = golden_compat
     if not fast:
@@ -38,6 +40,10 @@ def default_run(golden_compat: bool = True, fast: bool = True, frozen=None, inte
         cfg.process_noise_rw_var = np.square(cfg.process_noise_rw_std)
     if frozen is not None:
         cfg.frozen_dofs = list(frozen)
+    if with_notch:
+        cfg.camera.with_notch = cfg.with_notch = True
+    if max_vals is not None:
+        cfg.max_vals = max_vals
     probe = SimpleProbe(cfg.model.length, cfg.model.angle)
     cfg.update_dofs(probe)
     cam = create_camera(cfg)
