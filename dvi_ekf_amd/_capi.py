@@ -24,6 +24,17 @@ class Params(C.Structure):
     ]
 
 
+class Schedule(C.Structure):
+    """dvi_eskf_schedule"""
+    _fields_ = [
+        ("n_epochs", C.c_int64), ("n_pred", C.POINTER(C.c_int32)),
+        ("dt", C.c_void_p), ("dt_per_instance", C.c_int),
+        ("om", C.c_void_p), ("acc", C.c_void_p), ("imu_per_instance", C.c_int),
+        ("pos", C.c_void_p), ("quat_xyzw", C.c_void_p), ("notch", C.c_void_p), ("meas_per_instance", C.c_int),
+        ("status", C.c_void_p), ("t_log", C.POINTER(C.c_double)), ("rows_out", C.c_void_p),
+    ]
+
+
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
 _dp = C.POINTER(C.c_double)
 _hpp = C.POINTER(C.c_void_p)
@@ -44,7 +55,9 @@ SIGNATURES = {
     "dvi_eskf_update": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_step": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_epoch": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dvi_eskf_run_epochs": (_i, [_vp, C.POINTER(Schedule), _vp]),
     "dvi_eskf_get_calibration": (_i, [_vp, _vp, _vp]),
+    "dvi_eskf_gather_calibration": (_i, [_vp, _vp, _vp, _vp]),
     "dvi_eskf_flush": (_i, [_vp, _vp]),
     "dvi_eskf_raw_P": (_vp, [_vp]),
     "dvi_eskf_raw_x": (_vp, [_vp]),

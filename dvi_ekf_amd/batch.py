@@ -218,6 +218,59 @@ class BatchedESKF:
                                            _ptr(tn), per, _ptr(K), _ptr(status), self._stream()), "dvi_eskf_step")
         return status, K
 
+    def run_epochs(self, n_pred, dt, om, acc, pos, quat, notch, t_log=None):
+        """A whole run (Filter.run, Filter.py:144-168) enqueued by one call: epoch e = n_pred[e]
+        predicts + the update with measurement e.  dt [total] | [total,B]; om/acc [total,3] |
+        [total,B,3]; pos [E,3] | [E,B,3]; quat [E,4] | [E,B,4]; notch [E] | [E,B].
+        Returns (status [E,B] int32, rows [E,B,30] or None); rows are the trajectory-log rows
+        after every update when their time stamps ``t_log`` [E] are given."""
+        n_pred = np.ascontiguousarray(np.asarray(n_pred, dtype=np.int32))
+        E, total = int(n_pred.shape[0]), int(n_pred.sum())
+
+        def dev(a):
+            t = a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a))
+            return t.to(self.device, self.dtype).contiguous()
+
+        tdt, tom, tac, tp, tq, tn = dev(dt), dev(om), dev(acc), dev(pos), dev(quat), dev(notch)
+        pdt = 1 if tdt.dim() == 2 else 0
+        pim = 1 if tom.dim() == 3 else 0
+        per = 1 if tp.dim() == 3 else 0
+        B = self.batch
+        if tdt.shape != ((total, B) if pdt else (total,)):
+            raise ValueError("dt must be [sum(n_pred)] or [sum(n_pred),B]")
+        if tom.shape != ((total, B, 3) if pim else (total, 3)) or tac.shape != tom.shape:
+            raise ValueError("om/acc must be [sum(n_pred),3] or [sum(n_pred),B,3]")
+        if tp.shape != ((E, B, 3) if per else (E, 3)) or tq.shape != ((E, B, 4) if per else (E, 4)) or \
+                tn.shape != ((E, B) if per else (E,)):
+            raise ValueError("pos/quat/notch must be [E,3]/[E,4]/[E] or [E,B,3]/[E,B,4]/[E,B]")
+        status = torch.zeros((E, B), dtype=torch.int32, device=self.device)
+        rows = tl = None
+        if t_log is not None:
+            tl = np.ascontiguousarray(np.asarray(t_log, dtype=np.float64))
+            if tl.shape != (E,):
+                raise ValueError("t_log must be [E]")
+            rows = torch.empty((E, B, 30), dtype=self.dtype, device=self.device)
+        sc = _capi.Schedule()
+        sc.n_epochs = E
+        sc.n_pred = n_pred.ctypes.data_as(C.POINTER(C.c_int32))
+        sc.dt, sc.dt_per_instance = _ptr(tdt), pdt
+        sc.om, sc.acc, sc.imu_per_instance = _ptr(tom), _ptr(tac), pim
+        sc.pos, sc.quat_xyzw, sc.notch, sc.meas_per_instance = _ptr(tp), _ptr(tq), _ptr(tn), per
+        sc.status = _ptr(status)
+        sc.t_log = tl.ctypes.data_as(C.POINTER(C.c_double)) if tl is not None else None
+        sc.rows_out = _ptr(rows)
+        _capi.check(self.lib.dvi_eskf_run_epochs(self._h, C.byref(sc), self._stream()), "dvi_eskf_run_epochs")
+        return status, rows
+
+    def gather_calibration(self, rccl_comm, world_size: int) -> torch.Tensor:
+        """[world*B,6] calibration estimates of every rank: ncclAllGather on the caller's
+        communicator (an ``ncclComm_t`` as an integer / c_void_p).  With torch.distributed use
+        ``dvi_ekf_amd.dist.gather_calibration`` instead -- same collective through the process group."""
+        out = torch.empty((int(world_size) * self.batch, 6), dtype=self.dtype, device=self.device)
+        _capi.check(self.lib.dvi_eskf_gather_calibration(self._h, _ptr(out), C.c_void_p(int(rccl_comm)), self._stream()),
+                    "dvi_eskf_gather_calibration")
+        return out
+
     def epoch(self, dt, om, acc, pos, quat, notch, want_gain: bool = False):
         """n predicts then one update in a single launch (Filter.run_one_epoch).
         dt [n] | [n,B]; om/acc [n,3] | [n,B,3]."""

@@ -2,6 +2,8 @@
 // records of a batch of filter instances; never throws, never frees caller memory.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <vector>
 #include <cstring>
@@ -338,6 +340,85 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_pi, const voi
                    const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out, int32_t* status,
                    void* stream) {
     return step_common(h, n_pred, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream);
+}
+
+int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) {
+    if (!h || !sc || sc->n_epochs < 0) return DVI_ESKF_EINVAL;
+    if (sc->n_epochs == 0) return DVI_ESKF_OK;
+    if (!sc->n_pred || !sc->pos || !sc->quat_xyzw || !sc->notch) return DVI_ESKF_EINVAL;
+    if (sc->rows_out && !sc->t_log) return DVI_ESKF_EINVAL;
+    int64_t total = 0;
+    for (int64_t e = 0; e < sc->n_epochs; ++e) {
+        if (sc->n_pred[e] < 0) return DVI_ESKF_EINVAL;
+        total += sc->n_pred[e];
+    }
+    if (total > 0 && (!sc->dt || !sc->om || !sc->acc)) return DVI_ESKF_EINVAL;
+    const size_t es = elem_size(h->dtype);
+    const size_t B = (size_t)h->B;
+    const size_t dt_row = (sc->dt_per_instance ? B : 1) * es;
+    const size_t imu_row = (sc->imu_per_instance ? B : 1) * 3 * es;
+    const size_t mrow = sc->meas_per_instance ? B : 1;
+    const char* dt = static_cast<const char*>(sc->dt);
+    const char* om = static_cast<const char*>(sc->om);
+    const char* acc = static_cast<const char*>(sc->acc);
+    const char* pos = static_cast<const char*>(sc->pos);
+    const char* quat = static_cast<const char*>(sc->quat_xyzw);
+    const char* notch = static_cast<const char*>(sc->notch);
+    size_t off = 0;
+    for (int64_t e = 0; e < sc->n_epochs; ++e) {
+        const int n = sc->n_pred[e];
+        int rc = step_common(h, n, 1, n ? dt + off * dt_row : nullptr, sc->dt_per_instance, n ? om + off * imu_row : nullptr,
+                             n ? acc + off * imu_row : nullptr, sc->imu_per_instance, pos + (size_t)e * mrow * 3 * es,
+                             quat + (size_t)e * mrow * 4 * es, notch + (size_t)e * mrow * es, sc->meas_per_instance,
+                             nullptr, sc->status ? sc->status + (size_t)e * B : nullptr, stream);
+        if (rc != DVI_ESKF_OK) return rc;
+        if (sc->rows_out) {
+            rc = dvi_eskf_log_rows(h, sc->t_log[e], static_cast<char*>(sc->rows_out) + (size_t)e * B * 30 * es, stream);
+            if (rc != DVI_ESKF_OK) return rc;
+        }
+        off += (size_t)n;
+    }
+    return DVI_ESKF_OK;
+}
+
+namespace {
+// RCCL is bound at first use: the library must call into the SAME RCCL image that made the
+// caller's communicator (a process that imported torch already holds one), and a filter
+// process that never gathers should not have to load RCCL at all.
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+nccl_all_gather_fn bind_all_gather() {
+    static nccl_all_gather_fn fn = []() -> nccl_all_gather_fn {
+        void* sym = dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!sym) {
+            void* lib = dlopen("librccl.so.1", RTLD_LAZY | RTLD_NOLOAD);     // already in the process?
+            if (!lib) lib = dlopen("librccl.so", RTLD_LAZY | RTLD_NOLOAD);
+            if (!lib) lib = dlopen("librccl.so.1", RTLD_LAZY | RTLD_LOCAL);
+            if (!lib) lib = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
+            if (lib) sym = dlsym(lib, "ncclAllGather");
+        }
+        return reinterpret_cast<nccl_all_gather_fn>(sym);
+    }();
+    return fn;
+}
+}  // namespace
+
+int dvi_eskf_gather_calibration(dvi_eskf* h, void* dofs_all, void* rccl_comm, void* stream) {
+    if (!h || !dofs_all || !rccl_comm) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    nccl_all_gather_fn all_gather = bind_all_gather();
+    if (!all_gather) return DVI_ESKF_EHIP;
+    const size_t es = elem_size(h->dtype);
+    const size_t count = (size_t)h->B * 6;
+    void* local = nullptr;                                  // the send block must not alias the receive buffer
+    if (hipMallocAsync(&local, count * es, (hipStream_t)stream) != hipSuccess) return DVI_ESKF_ENOMEM;
+    int rc = dvi_eskf_get_calibration(h, local, stream);
+    if (rc == DVI_ESKF_OK) {
+        const int nccl_dtype = h->dtype == DVI_ESKF_F64 ? 8 /* ncclFloat64 */ : 7 /* ncclFloat32 */;
+        if (all_gather(local, dofs_all, count, nccl_dtype, rccl_comm, (hipStream_t)stream) != 0) rc = DVI_ESKF_EHIP;
+    }
+    (void)hipFreeAsync(local, (hipStream_t)stream);
+    return rc;
 }
 
 int dvi_eskf_flush(dvi_eskf* h, void* stream) {

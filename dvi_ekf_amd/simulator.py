@@ -148,11 +148,7 @@ class Simulator:
                           hold_frozen=bool(getattr(self.config, "golden_compat", False)))
         dev.set_noise_per_instance(q, r)
         dev.set_state(x=np.tile(ri.x0, (S, 1)), P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
-        ip = 0
-        for k in range(len(ri.t_meas)):
-            n = int(ri.n_pred[k])
-            dev.epoch(ri.dt[ip:ip + n], ri.om[ip:ip + n], ri.acc[ip:ip + n], ri.pos[k], ri.quat[k], ri.notch[k])
-            ip += n
+        dev.run_epochs(ri.n_pred, ri.dt, ri.om, ri.acc, ri.pos, ri.quat, ri.notch)   # Filter.run, one call
         gt = torch.as_tensor(np.asarray(self.config.gt_imu_dofs, dtype=float), device=dev.device)
         d = dev.calibration() - gt
         return ((d * d).sum(dim=1) / 6).cpu().numpy()               # Filter.calculate_dof_metric (Filter.py:452-455)

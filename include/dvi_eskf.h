@@ -127,10 +127,41 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_per_instance,
                    const void* acc, int imu_per_instance, const void* pos, const void* quat_xyzw,
                    const void* notch, int meas_per_instance, void* K_out, int32_t* status, void* stream);
 
+/* Filter.run (Filter.py:144-168): a whole run -- every camera frame's epoch -- enqueued by one
+ * call, so that a long run costs one trip through the host binding instead of one per frame.
+ * Epoch e consumes n_pred[e] consecutive IMU samples and measurement e; same kernels, same
+ * results, bit for bit, as n_epochs calls of dvi_eskf_epoch. */
+typedef struct dvi_eskf_schedule {
+    int64_t n_epochs;
+    const int32_t* n_pred;  /* HOST  [n_epochs]  IMU samples in front of each camera frame (>= 0) */
+    const void* dt;         /* device [total] | [total,B],     total = sum(n_pred)                 */
+    int dt_per_instance;
+    const void* om;         /* device [total,3] | [total,B,3]                                      */
+    const void* acc;
+    int imu_per_instance;
+    const void* pos;        /* device [n_epochs,3] | [n_epochs,B,3]                                */
+    const void* quat_xyzw;  /* device [n_epochs,4] | [n_epochs,B,4]  raw measurement quaternions   */
+    const void* notch;      /* device [n_epochs]   | [n_epochs,B]                                  */
+    int meas_per_instance;
+    int32_t* status;        /* NULL or device int32 [n_epochs,B]: the status word of every update  */
+    const double* t_log;    /* HOST  [n_epochs] time stamps of the log rows; needed with rows_out  */
+    void* rows_out;         /* NULL or device [n_epochs,B,30]: dvi_eskf_log_rows after every update
+                               (Filter.update appends to the trajectory log, Filter.py:394)       */
+} dvi_eskf_schedule;
+int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sched, void* stream);
+
 /* The estimated calibration parameters, i.e. state.dofs (Filter.calculate_dof_metric,
- * Filter.py:452-455): dofs_out [B,6].  The multi-GPU gather (RCCL all-gather of this
- * buffer) is done by the caller -- see dvi_ekf_amd/dist.py. */
+ * Filter.py:452-455): dofs_out [B,6]. */
 int dvi_eskf_get_calibration(const dvi_eskf* h, void* dofs_out, void* stream);
+
+/* The one collective of a multi-GPU run (instances are independent): all-gather of
+ * the calibration estimates of every rank.  dofs_all [world*B,6] in the handle's dtype, rank r's
+ * block at rows r*B..; every rank must hold the same batch size.  rccl_comm is the caller's
+ * ncclComm_t; the call is ncclAllGather on `stream`, RCCL being bound at first use from the
+ * library image already in the process (or librccl.so.1).  DVI_ESKF_EHIP if RCCL cannot be
+ * bound or reports an error.  Python callers with torch.distributed use dvi_ekf_amd/dist.py
+ * (same collective through the process group). */
+int dvi_eskf_gather_calibration(dvi_eskf* h, void* dofs_all, void* rccl_comm, void* stream);
 
 /* The error injection of an update (state.py:46-60) is deferred: it is applied by the next
  * predict/update/step/epoch call, or by any call that reads or replaces the state (get_state,

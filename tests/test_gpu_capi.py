@@ -1,6 +1,7 @@
 """C-ABI behaviour on a real device: argument validation (negative codes, nothing thrown),
 deferred-injection bookkeeping, raw buffer views."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -84,3 +85,106 @@ def test_flush_and_raw_views():
     st = f.get_state()
     assert st["x"].shape == (3, 26) and st["P"].shape == (3, 24, 24)
     assert torch.equal(st["P"], st["P"].transpose(1, 2))          # stored as its lower triangle
+
+
+def test_run_epochs_equals_epoch_by_epoch():
+    """dvi_eskf_run_epochs (Filter.run in one call) == n calls of dvi_eskf_epoch, bit for bit; status and
+    log rows per epoch; ragged schedule (an epoch without IMU samples, epochs of different length)."""
+    from tests.helpers import default_run
+    from dvi_ekf_amd.batch import BatchedESKF
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False)
+    B = 5
+    f = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so,
+                    hold_frozen=False)
+    f.set_noise(Q, R)
+    rng = np.random.default_rng(7)
+    x0 = np.tile(ri.x0, (B, 1))
+    x0[:, 10:13] += rng.normal(0, 0.02, (B, 3))
+    x0[:, 13:16] += rng.normal(0, 2.0, (B, 3))
+    f.set_state(x=x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    g = f.clone()
+    n_pred = np.array([10, 0, 3, 17, 10, 1], dtype=np.int32)       # ragged on purpose
+    E, total = len(n_pred), int(n_pred.sum())
+    # per-instance measurements, shared IMU stream
+    pos = ri.pos[:E, None, :] + rng.normal(0, 1e-3, (E, B, 3))
+    quat = np.repeat(ri.quat[:E, None, :], B, axis=1)
+    notch = rng.normal(0, 1e-3, (E, B))
+    t_log = ri.t_meas[:E]
+    status, rows = f.run_epochs(n_pred, ri.dt[:total], ri.om[:total], ri.acc[:total], pos, quat, notch, t_log=t_log)
+    off = 0
+    for e in range(E):
+        n = int(n_pred[e])
+        if n:
+            st, _ = g.epoch(ri.dt[off:off + n], ri.om[off:off + n], ri.acc[off:off + n], pos[e], quat[e], notch[e])
+        else:
+            st, _ = g.update(pos[e], quat[e], notch[e])
+        off += n
+        assert torch.equal(status[e], st)
+        assert torch.equal(rows[e], g.log_rows(float(t_log[e])))
+    sf, sg = f.get_state(), g.get_state()
+    for key in sf:
+        assert torch.equal(sf[key], sg[key]), key
+    assert int(status.abs().sum()) == 0 and rows.shape == (E, B, 30) and bool(torch.isfinite(rows).all())
+    assert torch.equal(rows[:, :, 0].cpu(), torch.as_tensor(t_log)[:, None].expand(E, B))
+
+    # broadcast measurements, no log
+    h1, h2 = g.clone(), g.clone()
+    st2, rows2 = h1.run_epochs([2, 2], ri.dt[:4], ri.om[:4], ri.acc[:4], ri.pos[:2], ri.quat[:2], ri.notch[:2])
+    assert rows2 is None and st2.shape == (2, B)
+    h2.epoch(ri.dt[:2], ri.om[:2], ri.acc[:2], ri.pos[0], ri.quat[0], ri.notch[0])
+    h2.epoch(ri.dt[2:4], ri.om[2:4], ri.acc[2:4], ri.pos[1], ri.quat[1], ri.notch[1])
+    assert torch.equal(h1.x, h2.x) and torch.equal(h1.get_state()["P"], h2.get_state()["P"])
+
+    # argument validation: codes, not exceptions
+    from dvi_ekf_amd import _capi
+    L = _capi.lib()
+    sc = _capi.Schedule()
+    assert L.dvi_eskf_run_epochs(f._h, None, None) == -1
+    sc.n_epochs = 0
+    assert L.dvi_eskf_run_epochs(f._h, C.byref(sc), None) == 0               # an empty run is a no-op
+    sc.n_epochs = 2
+    assert L.dvi_eskf_run_epochs(f._h, C.byref(sc), None) == -1              # no schedule arrays
+    bad = np.array([1, -1], dtype=np.int32)
+    sc.n_pred = bad.ctypes.data_as(C.POINTER(C.c_int32))
+    sc.pos = sc.quat_xyzw = sc.notch = 1                                      # never dereferenced: rejected first
+    assert L.dvi_eskf_run_epochs(f._h, C.byref(sc), None) == -1              # negative sample count
+    with pytest.raises(ValueError):
+        f.run_epochs([2, 2], ri.dt[:3], ri.om[:3], ri.acc[:3], ri.pos[:2], ri.quat[:2], ri.notch[:2])
+
+
+def test_gather_calibration_through_rccl():
+    """dvi_eskf_gather_calibration on a real RCCL communicator (one rank on the one GPU of the test box:
+    the collective degenerates to a copy, the binding, dtype and count are what is exercised)."""
+    from dvi_ekf_amd import _capi
+    f, ri, Q, R = _make(B=6, hold=False)
+    f.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])
+    L = _capi.lib()
+    assert L.dvi_eskf_gather_calibration(f._h, None, None, None) == -1
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so"):
+        for mode in (getattr(os, "RTLD_NOLOAD", 4) | os.RTLD_LAZY, os.RTLD_LAZY):
+            try:
+                rccl = C.CDLL(name, mode=mode)
+                break
+            except OSError:
+                continue
+        if rccl is not None:
+            break
+    if rccl is None:
+        rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        out = f.gather_calibration(comm.value, world_size=1)
+        torch.cuda.synchronize()
+        assert torch.equal(out, f.calibration())
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
