@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvi_eskf_log_rows": (_i, [_vp, C.c_double, _vp, _vp]),
     "dvi_eskf_imu_synthesize": (_i, [C.POINTER(Params), _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _dp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dvi_eskf_randn": (_i, [_i, _i, C.c_uint64, _i64, _i64, _i64, _i64, _i, _vp, _vp]),
     "dvi_eskf_strerror": (C.c_char_p, [_i]),
 }
 

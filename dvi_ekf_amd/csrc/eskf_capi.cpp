@@ -467,6 +467,23 @@ int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
 
+int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, int64_t n_instances, int64_t first_step,
+                   int64_t n_steps, int lanes, void* out, void* stream) {
+    if (kind < 0 || kind > 2 || first_instance < 0 || n_instances < 0 || first_step < 0 || n_steps < 0 || lanes < 0)
+        return DVI_ESKF_EINVAL;
+    if (first_step + n_steps > (int64_t)1 << 32) return DVI_ESKF_EINVAL;       // the step is one counter word
+    if (n_instances == 0 || n_steps == 0 || lanes == 0) return DVI_ESKF_OK;
+    if (!out) return DVI_ESKF_EINVAL;
+    if ((double)n_instances * (double)n_steps * (double)lanes >= 9.0e18) return DVI_ESKF_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return DVI_ESKF_ENODEV;
+    DeviceGuard g(device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_randn(kind, seed, first_instance, n_instances, first_step, n_steps, lanes, out,
+                                      (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
 const char* dvi_eskf_strerror(int code) {
     switch (code) {
         case DVI_ESKF_OK: return "ok";

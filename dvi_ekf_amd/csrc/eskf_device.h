@@ -88,4 +88,8 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
 
 hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream);
 
+// eskf_noise.hip -- kind: 0 = normals f64, 1 = normals f32, 2 = raw Philox words (uint32 x 4 per triple)
+hipError_t launch_randn(int kind, uint64_t seed, int64_t first_instance, int64_t n_instances, int64_t first_step,
+                        int64_t n_steps, int lanes, void* out, hipStream_t stream);
+
 }  // namespace eskf

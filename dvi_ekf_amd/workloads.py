@@ -4,8 +4,10 @@
 reference's default run (mandala0_mono, default config.yaml) on the 1:1 schedule --
 one predict at dt = 1.0 then one update per camera frame -- with per-instance
 perturbed initial extrinsic DOFs and per-instance additive Gaussian noise on the IMU
-and camera measurements.  Everything is generated on the device with torch's
-counter-based (Philox) generator, so the streams are reproducible from the seed.
+and camera measurements.  The noise is generated on the device by ``dvi_eskf_randn``
+(Philox4x32-10, key = seed * 2^32, counter = (instance, step, lane); Box-Muller -- the generator
+SURVEY.md 8(d) makes part of the contract): what an instance draws depends on its global index
+only, not on the batch or rank it is generated in.
 """
 from __future__ import annotations
 
@@ -16,6 +18,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
+from . import noise
 from .camera import create_camera
 from .config import Config
 from .imu import Imu
@@ -95,30 +98,33 @@ def monte_carlo_pairs(batch: int, horizon: int = 16, seed: int = 4, device="cuda
     if H > len(ri.t_meas):
         raise ValueError("horizon exceeds the trajectory")
     dev = torch.device(device)
-    g = torch.Generator(device=dev)
-    g.manual_seed((int(seed) << 32) + int(first_instance))
     t = lambda a: torch.as_tensor(np.asarray(a), dtype=dtype, device=dev)
     B = int(batch)
-    randn = lambda *shape: torch.randn(*shape, generator=g, device=dev, dtype=dtype)
+    key = int(seed) << 32
+    # lanes of one pair-step: 0..2 gyro, 3..5 accelerometer, 6..8 camera position, 9..11 camera
+    # attitude, 12 notch angle; the initial condition is drawn at step word IC_STEP, lanes 0..5
+    z_ic = noise.randn(key, first_instance, B, noise.IC_STEP, 1, 6, dtype=dtype, device=dev)[0]
+    z = noise.randn(key, first_instance, B, 0, H, 13, dtype=dtype, device=dev)
 
     x0 = t(ri.x0).repeat(B, 1)
     cov0 = np.sqrt(np.diag(ri.P0))
-    x0[:, 10:16] += randn(B, 6) * t(cov0[9:15])          # IC dofs = gt + N(0, cov0 dofs block)
+    x0[:, 10:16] += z_ic * t(cov0[9:15])                 # IC dofs = gt + N(0, cov0 dofs block)
     meas_std = np.sqrt(np.diag(R))
     dt = t(ri.dt[:H]).reshape(H, 1).repeat(1, B).contiguous()
-    om = t(ri.om[:H]).reshape(H, 1, 3) + randn(H, B, 3) * t(so)
-    acc = t(ri.acc[:H]).reshape(H, 1, 3) + randn(H, B, 3) * t(sa)
-    pos = t(ri.pos[:H]).reshape(H, 1, 3) + randn(H, B, 3) * t(meas_std[0:3])
+    om = t(ri.om[:H]).reshape(H, 1, 3) + z[:, :, 0:3] * t(so)
+    acc = t(ri.acc[:H]).reshape(H, 1, 3) + z[:, :, 3:6] * t(sa)
+    pos = t(ri.pos[:H]).reshape(H, 1, 3) + z[:, :, 6:9] * t(meas_std[0:3])
     # small-angle rotation noise on the measured attitude: q <- q * (theta/2, 1)
     q = t(ri.quat[:H]).reshape(H, 1, 4).repeat(1, B, 1)
-    th = randn(H, B, 3) * t(meas_std[3:6]) * 0.5
+    th = z[:, :, 9:12] * t(meas_std[3:6]) * 0.5
     qx, qy, qz, qw = q.unbind(-1)
     tx, ty, tz = th.unbind(-1)
     quat = torch.stack([qw * tx + qx + (qy * tz - qz * ty), qw * ty + qy + (qz * tx - qx * tz),
                         qw * tz + qz + (qx * ty - qy * tx), qw - (qx * tx + qy * ty + qz * tz)], dim=-1)
-    notch = t(ri.notch[:H]).reshape(H, 1).repeat(1, B).contiguous()
+    notch = (t(ri.notch[:H]).reshape(H, 1) + z[:, :, 12] * float(meas_std[6])).contiguous()
     if first_instance == 0:   # the reference run itself
         x0[0] = t(ri.x0)
         om[:, 0], acc[:, 0], pos[:, 0], quat[:, 0] = t(ri.om[:H]), t(ri.acc[:H]), t(ri.pos[:H]), t(ri.quat[:H])
+        notch[:, 0] = t(ri.notch[:H])
     return PairWorkload(cfg, ri, Q, R, sa, so, x0, t(ri.P0), t(ri.om0), t(ri.acc0), dt, om.contiguous(),
                         acc.contiguous(), pos.contiguous(), quat.contiguous(), notch)

@@ -197,6 +197,19 @@ int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int
                             int notch_per_sample, const double* dofs6, const void* p_CW, const void* v_CW,
                             void* om_B, void* acc_B, void* p_BW, void* R_WB, void* v_BW, void* stream);
 
+/* Noise for the synthetic batch workloads: standard normals that are a pure function
+ * of (seed, instance, step, lane) -- Philox4x32-10 with key = seed and counter = (instance lo,
+ * instance hi, step, lane), Box-Muller (cosine branch) on two 53-bit uniforms -- so that instance i
+ * of a sharded Monte-Carlo run (Simulator / montecarlo, configs #2 and #4) draws the numbers it
+ * draws in the unsharded run.  Stateless.  out: device [n_steps, n_instances, lanes];
+ * kind DVI_ESKF_RANDN_F64 / _F32: normals; DVI_ESKF_RANDN_BITS: the four raw 32-bit Philox words of
+ * every triple, uint32 [n_steps, n_instances, lanes, 4] (for known-answer tests). */
+#define DVI_ESKF_RANDN_F64 0
+#define DVI_ESKF_RANDN_F32 1
+#define DVI_ESKF_RANDN_BITS 2
+int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, int64_t n_instances,
+                   int64_t first_step, int64_t n_steps, int lanes, void* out, void* stream);
+
 /* Covariance kernel selector (for experiments and cross-checks).
  * DVI_ESKF_LANES_ROWS (default): row-resident kernel -- lane i of an instance keeps row i of P in
  * registers, 32 lanes per instance, two instances per wavefront.

@@ -83,14 +83,14 @@ def test_config3_predict_only_fp32_one_million_instances():
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
     f = _filter(cfg, Q, R, sa, so, B, False, dtype=torch.float32)
     f.set_state(x=ri.x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
-    g = torch.Generator(device="cuda")
-    g.manual_seed(3)
+    from dvi_ekf_amd import noise
     prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, False, sa, so, Q, R)
     sample = np.linspace(0, B - 1, 64).astype(np.int64)
     o = c_oracle.OracleBatch(prm, np.tile(ri.x0, (64, 1)), ri.P0, ri.om0, ri.acc0)
-    for _ in range(4):
-        om = torch.randn((B, 3), generator=g, device="cuda", dtype=torch.float32) * 0.05
-        acc = torch.randn((B, 3), generator=g, device="cuda", dtype=torch.float32)
+    for step in range(4):
+        z = noise.randn(3 << 32, 0, B, step, 1, 6, dtype=torch.float32, device="cuda")[0]   # seed 3
+        om = (z[:, 0:3] * 0.05).contiguous()
+        acc = z[:, 3:6].contiguous()
         f.predict(1e-3, om, acc)
         o.predict(1e-3, om[sample].double().cpu().numpy(), acc[sample].double().cpu().numpy())
     st = f.get_state(("x", "P"))

@@ -30,9 +30,10 @@ def config3(B):
                     hold_frozen=True, dtype=torch.float32, device=dev)
     f.set_noise(Q, R)
     f.set_state(x=np.tile(ri.x0, (B, 1)), P=ri.P0, om_old=np.tile(ri.om0, (B, 1)), acc_old=np.tile(ri.acc0, (B, 1)))
-    g = torch.Generator(device=dev); g.manual_seed(3)
-    om = 0.05 * torch.randn((B, 3), generator=g, device=dev, dtype=torch.float32)
-    acc = 1.0 * torch.randn((B, 3), generator=g, device=dev, dtype=torch.float32)
+    from dvi_ekf_amd import noise
+    z = noise.randn(3 << 32, 0, B, 0, 1, 6, dtype=torch.float32, device=dev)[0]     # seed 3
+    om = (0.05 * z[:, 0:3]).contiguous()
+    acc = (1.0 * z[:, 3:6]).contiguous()
     dt = torch.full((B,), 1e-3, device=dev, dtype=torch.float32)
     t = _time(lambda: f.predict(dt, om, acc), 256)
     ok = bool(torch.isfinite(f.x).all())
@@ -74,11 +75,13 @@ def config5(B=8192, frames=64):
     wl = monte_carlo_pairs(B, horizon=4, seed=5, device=dev)
     f = wl.make_filter(dtype=torch.float32)
     snap = f.clone()
-    g = torch.Generator(device=dev); g.manual_seed(5)
+    from dvi_ekf_amd import noise
     counts = [33, 33, 34]
     dts = [torch.full((n,), 1e-3, device=dev, dtype=torch.float32) for n in counts]
-    oms = [0.05 * torch.randn((n, 3), generator=g, device=dev, dtype=torch.float32) for n in counts]
-    accs = [1.0 * torch.randn((n, 3), generator=g, device=dev, dtype=torch.float32) for n in counts]
+    z = noise.randn(5 << 32, 0, 1, 0, sum(counts), 6, dtype=torch.float32, device=dev)[:, 0]   # one shared IMU stream
+    zs = torch.split(z, counts)
+    oms = [(0.05 * c[:, 0:3]).contiguous() for c in zs]
+    accs = [(1.0 * c[:, 3:6]).contiguous() for c in zs]
     pos, quat, notch = wl.pos[0].float(), wl.quat[0].float(), wl.notch[0].float()
     k = [0]
 
