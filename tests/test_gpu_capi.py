@@ -87,7 +87,8 @@ def test_flush_and_raw_views():
     assert torch.equal(st["P"], st["P"].transpose(1, 2))          # stored as its lower triangle
 
 
-def test_run_epochs_equals_epoch_by_epoch():
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_run_epochs_equals_epoch_by_epoch(dtype):
     """dvi_eskf_run_epochs (Filter.run in one call) == n calls of dvi_eskf_epoch, bit for bit; status and
     log rows per epoch; ragged schedule (an epoch without IMU samples, epochs of different length)."""
     from tests.helpers import default_run
@@ -95,7 +96,7 @@ def test_run_epochs_equals_epoch_by_epoch():
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False)
     B = 5
     f = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so,
-                    hold_frozen=False)
+                    hold_frozen=False, dtype=getattr(torch, dtype))
     f.set_noise(Q, R)
     rng = np.random.default_rng(7)
     x0 = np.tile(ri.x0, (B, 1))
@@ -125,7 +126,7 @@ def test_run_epochs_equals_epoch_by_epoch():
     for key in sf:
         assert torch.equal(sf[key], sg[key]), key
     assert int(status.abs().sum()) == 0 and rows.shape == (E, B, 30) and bool(torch.isfinite(rows).all())
-    assert torch.equal(rows[:, :, 0].cpu(), torch.as_tensor(t_log)[:, None].expand(E, B))
+    assert torch.equal(rows[:, :, 0].cpu(), torch.as_tensor(t_log).to(rows.dtype)[:, None].expand(E, B))
 
     # broadcast measurements, no log
     h1, h2 = g.clone(), g.clone()
