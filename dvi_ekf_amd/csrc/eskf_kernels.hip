@@ -566,10 +566,16 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
         const T f = (nv == T(0)) ? T(0) : ang / nv;
         T* gr = reinterpret_cast<T*>(a.res) + bo * 8;
+        T r[7];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { gr[i] = gpos[i] - s.pc[i]; gr[3 + i] = f * qe[i]; }
-        gr[6] = ang_notch - s.notch[0];
-        gr[7] = flag;                                         // asin argument was clamped
+        for (int i = 0; i < 3; ++i) { r[i] = gpos[i] - s.pc[i]; r[3 + i] = f * qe[i]; }
+        r[6] = ang_notch - s.notch[0];
+        // a NaN / inf measurement or state propagates exactly as it does in the reference (NumPy
+        // arithmetic, no check); the instance is flagged, its neighbours are not affected
+        if (!t_finite(r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6])) flag = T(1);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gr[i] = r[i];
+        gr[7] = flag;                                         // asin argument was clamped, or non-finite residual
     }
     if (a.n_pred > 0 || a.apply_pending) store_state(xs, a.B, bo, s);
 }

@@ -44,7 +44,9 @@ extern "C" {
 /* per-instance status word written by update / step */
 #define DVI_ESKF_STATUS_SINGULAR 1  /* innovation covariance not factorisable: state and P left
                                        untouched -- the `return None` path of Filter.py:356-361 */
-#define DVI_ESKF_STATUS_NONFINITE 2 /* asin argument clamped or non-finite value seen           */
+#define DVI_ESKF_STATUS_NONFINITE 2 /* asin argument clamped, or a NaN / inf residual (measurement
+                                       or state): it propagates into THIS instance as NumPy lets it
+                                       in the reference; other instances are unaffected          */
 
 typedef struct dvi_eskf dvi_eskf;
 

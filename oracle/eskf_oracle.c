@@ -469,6 +469,9 @@ int eskf_oracle_update(const eskf_oracle_params* prm, double* x, double* P, cons
     double ang = asin(nv);                                               /* Quaternion.py:138-147 */
     for (int i = 0; i < 3; ++i) res[3 + i] = (ang == 0.0) ? 0.0 : ang * (qe[i] / nv);
     res[6] = ang_notch - x[16];
+    /* NumPy propagates a NaN / inf measurement or state silently (no check in Filter.update); the
+     * status word records it */
+    if (!isfinite(res[0] + res[1] + res[2] + res[3] + res[4] + res[5] + res[6])) status |= ESKF_ORACLE_NONFINITE;
 
     double e[NE];
     for (int i = 0; i < NE; ++i) {

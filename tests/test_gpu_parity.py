@@ -393,3 +393,48 @@ def test_fp32_variant_tracks_oracle_loosely():
     s = f.get_state()
     assert np.abs(s["x"].cpu().numpy() - o.x).max() <= 2e-5 * np.abs(o.x).max()
     assert np.abs(s["P"].cpu().numpy() - o.P).max() <= 2e-4 * np.abs(o.P).max()
+
+
+@pytest.mark.parametrize("lpi", [None, 2, 32])
+def test_non_finite_measurement_stays_in_its_instance(lpi):
+    """A NaN / inf camera measurement propagates into the state of ITS instance exactly as NumPy
+    lets it in the reference (Filter.update has no check) and is reported in the status word; every
+    other instance of the batch -- including the one sharing its wavefront -- is bit for bit what it
+    is without the bad measurement.  The oracle flags the same instances."""
+    B = 70
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False, frozen=(0,) * 6)
+    x0 = _perturbed_x0(ri, B)
+    f = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=lpi)
+    o = _oracle(cfg, ri, Q, R, sa, so, B, False, x0)
+    for i in range(3):
+        f.predict(ri.dt[i], ri.om[i], ri.acc[i])
+        o.predict(ri.dt[i], ri.om[i], ri.acc[i])
+    clean = f.clone()
+    pos = np.tile(ri.pos[0], (B, 1))
+    quat = np.tile(ri.quat[0], (B, 1))
+    notch = np.full(B, ri.notch[0])
+    bad = {5: "pos", 33: "quat", 64: "notch", 69: "inf"}
+    pos_b, quat_b, notch_b = pos.copy(), quat.copy(), notch.copy()
+    pos_b[5, 1] = np.nan
+    quat_b[33, 2] = np.nan
+    notch_b[64] = np.nan
+    pos_b[69, 0] = np.inf
+    st, _ = f.update(pos_b, quat_b, notch_b)
+    stc, _ = clean.update(pos, quat, notch)
+    st, stc = st.cpu().numpy(), stc.cpu().numpy()
+    good = np.array([b not in bad for b in range(B)])
+    assert (stc == 0).all() and (st[good] == 0).all()
+    assert all(st[b] & 2 for b in bad), st[list(bad)]
+    sf, sc = f.get_state(), clean.get_state()
+    for key in ("x", "P"):
+        a, c = sf[key].cpu().numpy(), sc[key].cpu().numpy()
+        assert np.array_equal(a[good], c[good]), key
+    xs = sf["x"].cpu().numpy()
+    assert all(not np.isfinite(xs[b]).all() for b in bad)
+    o.update(pos_b, quat_b, notch_b)
+    assert all(o.status[b] & 2 for b in bad) and (o.status[good] == 0).all()
+    assert np.abs(xs[good] - o.x[good]).max() <= 1e-9
+    # the next step keeps the damage where it is
+    f.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[1], ri.quat[1], ri.notch[1])
+    clean.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[1], ri.quat[1], ri.notch[1])
+    assert torch.equal(f.x[torch.as_tensor(good)], clean.x[torch.as_tensor(good)])
