@@ -192,3 +192,41 @@ def test_random_covariances_row_resident_vs_lds_image_vs_oracle():
     eP = max(_rel(a["P"][i].cpu().numpy(), o.P[i], 1) for i in range(n))
     print(f"random SPD, rows vs oracle: x {ex:.2e} P {eP:.2e}")
     assert ex <= 1e-8 and eP <= 1e-8
+
+
+def test_eight_million_instances_address_range():
+    """B = 2^23 fp64: the packed covariance record (B x 300 words = 20 GB) lies beyond 2^31 elements
+    and 2^34 bytes, so every 32-bit shortcut in the kernels' addressing would show here.  The batch is
+    a 96-instance pattern repeated; after two predict+update pairs (the second one goes through the P the
+    first one stored) instances at the start, around the 2^31-element boundary, and at the very end
+    must equal the 96-instance batch bit for bit."""
+    B, M = 1 << 23, 96
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 120e9:
+        pytest.skip("needs ~100 GB of device memory")
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False, frozen=(0,) * 6)
+    rng = np.random.default_rng(23)
+    xm = np.tile(ri.x0, (M, 1))
+    xm[1:, 10:13] += rng.normal(0, np.radians(3.0), (M - 1, 3))
+    xm[1:, 13:16] += rng.normal(0, 5.0, (M - 1, 3))
+    small = _filter(cfg, Q, R, sa, so, M, False)
+    small.set_state(x=xm, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    big = _filter(cfg, Q, R, sa, so, B, False)
+    reps = (B + M - 1) // M
+    xb = torch.as_tensor(xm, device="cuda").repeat(reps, 1)[:B].contiguous()
+    big.set_state(x=xb, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    del xb
+    torch.cuda.empty_cache()
+    for k in range(2):
+        sb, _ = big.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
+        ss, _ = small.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
+    assert int(sb.abs().max()) == 0 and int(ss.abs().max()) == 0
+    xs, xbig = small.x, big.x
+    boundary = (1 << 31) // 300                       # first instance whose record starts beyond 2^31 elements
+    for start in (0, boundary - 200, boundary + 200, B // 2, B - 2 * M, B - M - 1):
+        start -= start % M                            # align to the pattern
+        assert torch.equal(xbig[start:start + M], xs), start
+    tail = B - (B // M) * M                           # the last, partial repetition
+    assert torch.equal(xbig[B - tail:], xs[:tail])
+    assert torch.equal(big.calibration()[B - tail:], small.calibration()[:tail])
+    assert bool(torch.isfinite(xbig).all())
