@@ -438,3 +438,67 @@ def test_non_finite_measurement_stays_in_its_instance(lpi):
     f.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[1], ri.quat[1], ri.notch[1])
     clean.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[1], ri.quat[1], ri.notch[1])
     assert torch.equal(f.x[torch.as_tensor(good)], clean.x[torch.as_tensor(good)])
+
+
+def _random_unit_quats(rng, n):
+    q = rng.standard_normal((n, 4))
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("frozen,hold,dt_scale,seed", [((0,) * 6, False, 0.1, 1), ((1, 0, 1, 0, 0, 1), False, 1.0, 2),
+                                                       ((1,) * 6, True, 1.0, 3), ((0,) * 6, False, 1e-3, 4)])
+def test_random_configurations_single_step_parity(frozen, hold, dt_scale, seed):
+    """States nowhere near the reference trajectory: random attitudes (all four branches of the
+    Markley matrix-to-quaternion conversion, both signs of w), joint angles over +-pi, notch angle and
+    rates, random previous / current IMU samples, per-instance dt, measurements up to a half-turn away
+    from the state, random SPD covariances -- one predict and one update against the C oracle, every
+    instance with its own inputs."""
+    B = 2048
+    rng = np.random.default_rng(1000 + seed)
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=frozen)
+    x0 = np.zeros((B, 26))
+    x0[:, 0:3] = rng.normal(0, 30.0, (B, 3))
+    x0[:, 3:6] = rng.normal(0, 5.0, (B, 3))
+    x0[:, 6:10] = _random_unit_quats(rng, B)
+    x0[:, 10:13] = rng.uniform(-np.pi, np.pi, (B, 3))
+    x0[:, 13:16] = rng.normal(0, 20.0, (B, 3))
+    x0[:, 16] = rng.uniform(-np.pi, np.pi, B)
+    x0[:, 17:19] = rng.normal(0, 0.1, (B, 2))
+    x0[:, 19:22] = rng.normal(0, 30.0, (B, 3))
+    x0[:, 22:26] = _random_unit_quats(rng, B)
+    A = rng.standard_normal((B, 24, 24)) * 10.0 ** rng.uniform(-2, 0, (B, 24, 1))
+    P0 = A @ A.transpose(0, 2, 1) / 24 + 1e-4 * np.eye(24)
+    om_old, acc_old = rng.normal(0, 0.5, (B, 3)), rng.normal(0, 20.0, (B, 3))
+    om, acc = rng.normal(0, 0.5, (B, 3)), rng.normal(0, 20.0, (B, 3))
+    dt = dt_scale * rng.uniform(0.5, 1.5, B)
+    pos = x0[:, 19:22] + rng.normal(0, 1.0, (B, 3))
+    quat = _random_unit_quats(rng, B) * rng.uniform(0.5, 2.0, (B, 1))        # raw, un-normalised
+    near = rng.random(B) < 0.5                                                # half of them near the camera state
+    quat[near] = x0[near, 22:26] + rng.normal(0, 0.05, (near.sum(), 4))
+    notch = rng.uniform(-np.pi, np.pi, B)
+    notch[near] = x0[near, 16] + rng.normal(0, 0.01, near.sum())
+    # a measurement quaternion is turned by the notch angle before it is compared (Filter.py:364-365)
+    for lpi in (None, 32):
+        f = _make(cfg, ri, Q, R, sa, so, B, hold, x0, lpi=lpi)
+        f.set_state(x=x0, P=P0, om_old=om_old, acc_old=acc_old)
+        o = _oracle(cfg, ri, Q, R, sa, so, B, hold, x0)
+        o.P[:] = P0
+        o.om_old[:] = om_old
+        o.acc_old[:] = acc_old
+        f.predict(dt, om, acc)
+        o.predict(dt, om, acc)
+        s = {k_: v.cpu().numpy() for k_, v in f.get_state().items()}
+        ex_p, eP_p = _rel(s["x"], o.x, B), _rel(s["P"], o.P, B)
+        st, _ = f.update(pos, quat, notch)
+        o.update(pos, quat, notch)
+        st = st.cpu().numpy()
+        assert ((st & 1) == 0).all() and ((o.status & 1) == 0).all()
+        assert np.array_equal(st & 2, o.status & 2)                            # same instances hit the asin clamp
+        s = {k_: v.cpu().numpy() for k_, v in f.get_state().items()}
+        ex_u, eP_u = _rel(s["x"], o.x, B), _rel(s["P"], o.P, B)
+        w_neg = int((s["x"][:, 9] < 0).sum())
+        print(f"random configurations frozen={frozen} hold={hold} dt~{dt_scale} kernel={lpi or 'rows'}: predict x {ex_p:.1e} "
+              f"P {eP_p:.1e}; update x {ex_u:.1e} P {eP_u:.1e}; clamped {int((st & 2 != 0).sum())}")
+        assert w_neg == 0                                                       # normalisation keeps w >= 0 (Quaternion.py:195-206)
+        assert ex_p <= 1e-11 and eP_p <= 1e-10
+        assert ex_u <= 1e-9 and eP_u <= 1e-8
