@@ -94,3 +94,58 @@ def test_device_log_rows_match_host_log_format():
             scale = np.maximum(1.0, np.abs(host))
             assert (np.abs(rows[b] - host) / scale).max() <= 1e-12, (k, b)
         f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])   # leaves an injection pending
+
+
+def test_device_imu_and_log_rows_at_random_configurations():
+    """f1 and f2 away from the reference run: random camera attitudes and rates, joint angles and notch
+    over +-pi with rates -- device IMU synthesis vs the host restatement; random states (attitudes
+    with Euler angles in every quadrant, near the +-90 deg pitch singularity included) -- device log
+    rows vs the host row."""
+    from scipy.spatial.transform import Rotation
+    from dvi_ekf_amd.state import State
+    from dvi_ekf_amd.traj import euler_measurement_row
+    from tests.test_gpu_parity import _make
+    rng = np.random.default_rng(11)
+    n = 512
+    R = Rotation.random(n, random_state=5).as_matrix()
+    om, acc, alp = rng.normal(0, 1.0, (n, 3)), rng.normal(0, 30.0, (n, 3)), rng.normal(0, 2.0, (n, 3))
+    p, v = rng.normal(0, 50.0, (n, 3)), rng.normal(0, 5.0, (n, 3))
+    notch = np.stack([rng.uniform(-np.pi, np.pi, n), rng.normal(0, 0.5, n), rng.normal(0, 0.5, n)], 1)
+    dofs = np.concatenate([rng.uniform(-np.pi, np.pi, 3), rng.normal(0, 20.0, 3)])
+    L, th = 50.0, np.radians(30.0)
+    om_d, acc_d, p_d, R_d, v_d = synthesize_on_device(R, om, acc, alp, notch, dofs, L, th, p_CW=p, v_CW=v)
+    worst = 0.0
+    for i in range(n):
+        fk = probe_fwkin(dofs, notch[i], L, th)
+        o, a = imu_measurement(R[i], om[i], acc[i], alp[i], fk)
+        pr, Rr, vr = imu_pose_from_camera([p[i], R[i], v[i], om[i], acc[i], alp[i]], fk)
+        for d, h in ((om_d[i], o), (acc_d[i], a), (p_d[i], pr), (R_d[i].reshape(3, 3), Rr), (v_d[i], vr)):
+            h = np.asarray(h, dtype=float).reshape(d.shape)
+            worst = max(worst, np.abs(d.cpu().numpy() - h).max() / max(1.0, np.abs(h).max()))
+    assert worst <= 1e-13, worst
+
+    B = 256
+    cfg, ri, Q, Rm, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    x = np.zeros((B, 26))
+    x[:, 0:6] = rng.normal(0, 30.0, (B, 6))
+    x[:, 6:10] = Rotation.random(B, random_state=6).as_quat()
+    x[:, 10:13] = rng.uniform(-np.pi, np.pi, (B, 3))
+    x[:, 13:16] = rng.normal(0, 20.0, (B, 3))
+    x[:, 16:19] = rng.normal(0, 1.0, (B, 3))
+    x[:, 19:22] = rng.normal(0, 30.0, (B, 3))
+    x[:, 22:26] = Rotation.random(B, random_state=7).as_quat()
+    # a few attitudes close to the pitch singularity of the xyz Euler angles
+    for j, pitch in enumerate((89.999, -89.999, 90.0 - 1e-7)):
+        x[j, 6:10] = Rotation.from_euler("xyz", [20.0, pitch, -30.0], degrees=True).as_quat()
+    x[:, 6:10] *= np.where(x[:, 9:10] < 0, -1.0, 1.0)
+    x[:, 22:26] *= np.where(x[:, 25:26] < 0, -1.0, 1.0)
+    f = _make(cfg, ri, Q, Rm, sa, so, B, False, x)
+    rows = f.log_rows(1.5).cpu().numpy()
+    for b in range(B):
+        host = np.array(euler_measurement_row(1.5, State.from_vector(x[b])), dtype=float)
+        ang = np.zeros(30, dtype=bool)
+        ang[[7, 8, 9, 23, 24, 25]] = True
+        d = np.abs(rows[b] - host)
+        d[ang] = np.minimum(d[ang], np.abs(d[ang] - 360.0))                  # +-180 deg is one angle
+        tol = np.where(ang, 1e-6 if b < 3 else 1e-9, 1e-12) * np.maximum(1.0, np.abs(host))
+        assert (d <= tol).all(), (b, np.argmax(d / tol), rows[b], host)
