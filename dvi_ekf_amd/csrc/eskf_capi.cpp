@@ -353,6 +353,13 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
         total += sc->n_pred[e];
     }
     if (total > 0 && (!sc->dt || !sc->om || !sc->acc)) return DVI_ESKF_EINVAL;
+    {   // size the Jacobian workspace for the longest epoch once, not epoch by epoch
+        int longest = 0;
+        for (int64_t e = 0; e < sc->n_epochs; ++e) longest = sc->n_pred[e] > longest ? sc->n_pred[e] : longest;
+        DeviceGuard g(h->device);
+        if (!g.ok) return DVI_ESKF_EHIP;
+        if (!ensure_jcap(h, longest)) return DVI_ESKF_ENOMEM;
+    }
     const size_t es = elem_size(h->dtype);
     const size_t B = (size_t)h->B;
     const size_t dt_row = (sc->dt_per_instance ? B : 1) * es;
