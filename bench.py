@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=65536, help="filter instances per GPU")
+    ap.add_argument("--strong", action="store_true",
+                    help="BASELINE config #4 as written: --batch is the TOTAL, sharded over the ranks (strong scaling); "
+                         "the default keeps --batch instances per GPU (weak scaling, what the driver's scaling run expects)")
     ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
     ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident; 64/32/24/16/12/8 = LDS-image kernel with that many lanes per instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,6 +153,10 @@ def main():
 
     from dvi_ekf_amd.workloads import monte_carlo_pairs
     B, H, K, W = args.batch, args.horizon, args.steps, args.warmup
+    if args.strong:
+        if B % world:
+            raise SystemExit("--strong: the total batch must divide evenly over the ranks")
+        B //= world
     wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, first_instance=rank * B)
     f = wl.make_filter()
     if args.lanes:
@@ -282,7 +289,7 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
