@@ -20,6 +20,8 @@
 //                (R_WB_old = Rm(q_old), Filter.py:227)
 //   J  [n][B][88], res [B][8], e [B][24], status [B]   workspace between the kernels
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 
 #include "eskf_device.h"
@@ -1353,6 +1355,53 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
                       "+v"(p[16]), "+v"(p[17]), "+v"(p[18]), "+v"(p[19]), "+v"(p[20]), "+v"(p[21]), "+v"(p[22]), "+v"(p[23])
                  : : "memory");
 }
+
+// ---- cross-lane broadcast without LDS (fp64, 32 lanes per instance) -------------------------------
+// An instance occupies two 16-lane DPP rows: rows 0..15 of P in the first, rows 16..23 (+ 8 shadow
+// lanes) in the second.  `row_newbcast:n` feeds lane n of the reader's own 16-lane row to every lane
+// of that row as a source operand of a DP-rate instruction at no extra cost, so a value that every lane
+// of the instance holds for its own row -- a column of P -- reaches all rows as `v_fmac_f64_dpp`
+// operands once both 16-lane rows carry it: spread_rows() makes X = (first row's values in both rows)
+// and Y = (second row's values in both rows) with one v_permlane16_swap per dword.
+// (Checked on gfx950 with variants of tools/-style micro-kernels: row_newbcast semantics, the swap's
+//  row pairing, and v_fmac_f64_dpp issuing at the rate of v_fmac_f64.)
+__device__ __forceinline__ void spread_rows(double v, double& X, double& Y) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    X = __hiloint2double(b[0], a[0]);
+    Y = __hiloint2double(b[1], a[1]);
+}
+// acc += (lane LANE of the reader's 16-lane row of src) * mul.  The wait states a DPP read needs after a
+// VALU write of its source / of EXEC are not inserted inside inline assembly: FIRST adds them.
+template <int LANE, bool FIRST = false>
+__device__ __forceinline__ void dpp_fmac(double& acc, double src, double mul) {
+    if (FIRST)
+        asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ double dpp_bcast(double src) {
+    double r;
+    asm volatile("s_nop 4\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
+    return r;
+}
+template <int J0, int J1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (J0 < J1) {
+        f(std::integral_constant<int, J0>{});
+        static_for<J0 + 1, J1>(f);
+    }
+}
+// float overloads: never instantiated on a taken path (the fp32 kernels keep the LDS exchange)
+__device__ __forceinline__ void spread_rows(float, float&, float&) {}
+template <int LANE, bool FIRST = false>
+__device__ __forceinline__ void dpp_fmac(float&, float, float) {}
+template <int LANE>
+__device__ __forceinline__ float dpp_bcast(float v) { return v; }
 }  // namespace rowk
 
 // Index tables of the row-resident kernel, computed at compile time and read from device memory (a few
@@ -1548,6 +1597,46 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
 #pragma unroll
         for (int m = 0; m < 7; ++m) E[m] = T(0);
         int napplied = 0;
+        // fp64, 32 lanes per instance: the column every lane needs is handed around as DPP operands
+        // (no LDS read-back, no barrier); the LDS copy is only written, for the take-back below
+        constexpr bool DPPU = LPI == 32 && sizeof(T) == 8;
+        if constexpr (DPPU) {
+            static_for<0, 7>([&](auto M) {
+                constexpr int m = decltype(M)::value;
+                constexpr int sm = sel[m];
+                const T pm = p[sm];
+                if (active) lds_store1(sB + m * 24 + row, pm);
+                T X, Y;                     // column sel_m of the current P: X rows 0..15, Y rows 16..23
+                spread_rows(pm, X, Y);
+                const T csel = dpp_bcast<(sm & 15)>(sm < 16 ? X : Y);
+                const T sv = csel + (PIN ? sN[13 + m] : prm.r[m]);
+                fail = fail || !(sv != T(0) && t_finite(sv));
+                if (!fail) {
+                    const T g = fast_rcp(sv);
+                    const T tau = (sR[m] - E[m]) * g;
+                    const T kk = pm * g;    // gain of this measurement, component `row`
+                    const T nkk = -kk;
+                    e += pm * tau;
+                    static_for<m + 1, 7>([&](auto M2) {
+                        constexpr int s2 = sel[decltype(M2)::value];
+                        dpp_fmac<(s2 & 15), decltype(M2)::value == m + 1>(E[decltype(M2)::value], s2 < 16 ? X : Y, tau);
+                    });
+                    // Joseph form with the optimal gain, Filter.py:383-384: p[j] -= kk * P[j][sel_m]
+                    static_for<12, 24>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        dpp_fmac<(j & 15), j == 12>(p[j], j < 16 ? X : Y, nkk);
+                    });
+                    static_for<0, 12>([&](auto J) {
+                        constexpr int j = decltype(J)::value;
+                        dpp_fmac<(j & 15)>(p[j], X, nkk);
+                    });
+                    napplied = m + 1;
+                }
+                pin_row(p);
+                asm volatile("" : "+v"(e), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
+            });
+            if (__builtin_expect(fail, 0)) group_sync();   // (the published columns are read below)
+        } else {
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
             T* cb = sB + m * 24;            // (the exchange image is idle during the update; the columns
@@ -1581,6 +1670,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
             // pivot chain and parks seven columns in scratch for the deferred row updates
             pin_row(p);
             asm volatile("" : "+v"(e), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
+        }
         }
         if (__builtin_expect(fail, 0)) {
             // take the applied measurements back, last first (the predicted covariance is restored
