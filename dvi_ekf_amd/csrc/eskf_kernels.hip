@@ -37,6 +37,8 @@ __device__ __forceinline__ double t_sqrt(double a) { return sqrt(a); }
 __device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
 __device__ __forceinline__ double t_asin(double a) { return asin(a); }
 __device__ __forceinline__ float t_asin(float a) { return asinf(a); }
+__device__ __forceinline__ double t_fma(double a, double b, double c) { return fma(a, b, c); }
+__device__ __forceinline__ float t_fma(float a, float b, float c) { return fmaf(a, b, c); }
 __device__ __forceinline__ bool t_finite(double a) { return isfinite(a); }
 __device__ __forceinline__ bool t_finite(float a) { return isfinite(a); }
 
@@ -1103,7 +1105,7 @@ __device__ __forceinline__ void fx_apply(const T* sJ, const T (&v)[24], T (&o)[2
 #pragma unroll
         for (int k = 0; k < 9; ++k) Th[k] = sJ[L_TH + k];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) o[6 + r] = Th[3 * r] * v[6] + Th[3 * r + 1] * v[7] + Th[3 * r + 2] * v[8];
+        for (int r = 0; r < 3; ++r) o[6 + r] = t_fma(Th[3 * r + 2], v[8], t_fma(Th[3 * r + 1], v[7], Th[3 * r] * v[6]));   // (explicit order: same bits as the DPP path)
     }
 #pragma unroll
     for (int k = 9; k < 15; ++k) o[k] = v[k];
@@ -1174,9 +1176,11 @@ __device__ __forceinline__ void fx_apply_store(const T* sJ, const T (&v)[24], T*
         for (int k = 0; k < 9; ++k) { A[k] = sJ[L_A + k]; Th[k] = sJ[L_TH + k]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            o[r] = v[r] + dt * v[3 + r];
+            // (fusions and order spelled out where the source form leaves the compiler a choice: the DPP
+            //  path performs exactly these operations, and the two lane layouts must give the same bits)
+            o[r] = t_fma(dt, v[3 + r], v[r]);
             o[3 + r] = v[3 + r] + A[3 * r] * v[6] + A[3 * r + 1] * v[7] + A[3 * r + 2] * v[8];
-            o[6 + r] = Th[3 * r] * v[6] + Th[3 * r + 1] * v[7] + Th[3 * r + 2] * v[8];
+            o[6 + r] = t_fma(Th[3 * r + 2], v[8], t_fma(Th[3 * r + 1], v[7], Th[3 * r] * v[6]));
         }
         if (active) {
 #pragma unroll
@@ -1197,7 +1201,7 @@ __device__ __forceinline__ void fx_apply_store(const T* sJ, const T (&v)[24], T*
             for (int k = 0; k < 3; ++k) Bm[k] = sJ[L_BM + 3 * r + k];
 #pragma unroll
             for (int k = 0; k < 6; ++k) Cm[k] = sJ[L_CM + 6 * r + k];
-            T u = dt * v[3 + r] + v[16 + r];
+            T u = t_fma(dt, v[3 + r], v[16 + r]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) u += Bm[k] * v[6 + k];
 #pragma unroll
@@ -1249,13 +1253,17 @@ __device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[2
         for (int k = 0; k < 9; ++k) { A[k] = sJ[L_A + k]; Th[k] = sJ[L_TH + k]; }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            o[r] = c[r] + dt * c[3 + r];
+            T x;
+            {
+#pragma clang fp contract(off)
+                x = dt * c[3 + r];          // rounded once, used twice (not fused into o[r])
+                o[r] = c[r] + x;
+            }
             o[3 + r] = c[3 + r] + A[3 * r] * c[6] + A[3 * r + 1] * c[7] + A[3 * r + 2] * c[8];
-            o[6 + r] = Th[3 * r] * c[6] + Th[3 * r + 1] * c[7] + Th[3 * r + 2] * c[8];
+            o[6 + r] = t_fma(Th[3 * r + 2], c[8], t_fma(Th[3 * r + 1], c[7], Th[3 * r] * c[6]));
             T Bm[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) Bm[k] = sJ[L_BM + 3 * r + k];
-            T x = dt * c[3 + r];
 #pragma unroll
             for (int k = 0; k < 3; ++k) x += Bm[k] * c[6 + k];
             u[r] = x;
@@ -1310,7 +1318,7 @@ __device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[2
 // P' += Fi Q Fi^T on the row-resident P: diagonal entries 3..14 <- Q[i-3], 17 <- Q[12]
 // (Filter.py:263-264,349); with gyro noise (tune mode) also the camera rows through N6 and theta
 // through Fi[6:9,3:6] = I
-template <typename T, bool PIN>
+template <typename T, bool PIN, bool GYRO = true>
 __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, const T* sN, int row, T (&p)[24]) {
     if (PIN) {      // diag(Q) of this instance sits in LDS (sN[0:13]); each lane needs the entry of its own row
         T qrow = T(0);
@@ -1319,12 +1327,16 @@ __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ,
 #pragma unroll
         for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? qrow : T(0);
         p[17] += (row == 17) ? qrow : T(0);
-    } else {
+    } else {        // (one selected value per lane: thirteen hoisted selects would sit in registers through the predict)
+        T qrow = T(0);
 #pragma unroll
-        for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? prm.qd[k] : T(0);
-        p[17] += (row == 17) ? prm.qd[12] : T(0);
+        for (int k = 0; k < 12; ++k) qrow = (row == 3 + k) ? prm.qd[k] : qrow;
+        qrow = (row == 17) ? prm.qd[12] : qrow;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) p[3 + k] += (row == 3 + k) ? qrow : T(0);
+        p[17] += (row == 17) ? qrow : T(0);
     }
-    if (prm.q_gyro) {
+    if (GYRO && prm.q_gyro) {
         const T* N6 = sJ + L_N6;
         if (row >= 18) {
             const int ar = row - 18;
@@ -1371,22 +1383,22 @@ __device__ __forceinline__ void spread_rows(double v, double& X, double& Y) {
     const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
     X = __hiloint2double(b[0], a[0]);
     Y = __hiloint2double(b[1], a[1]);
+    // A DPP read needs 2 wait states after a VALU write of its source, and inline assembly is opaque to
+    // the compiler's hazard recognizer: every DPP user depends on the outputs of this statement, so the
+    // wait states sit between the swap and all of them wherever the scheduler puts those
+    // (tools/check_dpp_hazards.py verifies the generated code).
+    asm("s_nop 1" : "+v"(X), "+v"(Y));
 }
-// acc += (lane LANE of the reader's 16-lane row of src) * mul.  The wait states a DPP read needs after a
-// VALU write of its source / of EXEC are not inserted inside inline assembly: FIRST adds them.
+// acc += (lane LANE of the reader's 16-lane row of src) * mul.  Not volatile: a pure function of its
+// operands, free to be interleaved with independent chains.
 template <int LANE, bool FIRST = false>
 __device__ __forceinline__ void dpp_fmac(double& acc, double src, double mul) {
-    if (FIRST)
-        asm volatile("s_nop 4\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                     : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
-    else
-        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                     : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
 }
 template <int LANE>
 __device__ __forceinline__ double dpp_bcast(double src) {
     double r;
-    asm volatile("s_nop 4\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
+    asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
     return r;
 }
 template <int J0, int J1, typename F>
@@ -1397,6 +1409,143 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 // float overloads: never instantiated on a taken path (the fp32 kernels keep the LDS exchange)
+// The Jacobian record of an instance spread over its 32 lanes (lane l holds words l, 32+l, 64+l -- the
+// registers the record is fetched into) and made reachable as DPP operands: X[k] / Y[k] carry the k-th
+// word of the lanes of the first / second 16-lane row in both rows.
+struct JRegs {
+    double X[3], Y[3];
+    // acc += J[W] * v
+    template <int W, bool FIRST = false>
+    __device__ __forceinline__ void mac(double& acc, double v) const {
+        constexpr int k = W >> 5, l = W & 31;
+        dpp_fmac<(l & 15), FIRST>(acc, l < 16 ? X[k] : Y[k], v);
+    }
+};
+// dst[0:24] = Fx v and o = Fx c: the operations of fx_apply_store / fx_apply_col in the same order (the two
+// lane layouts give the same bits), with the Jacobian entries as DPP operands instead of LDS reads
+__device__ __forceinline__ void fx_apply_store_dpp(const JRegs& J, const double (&v)[24], double* dst, bool active) {
+    {
+        double o[9];
+        static_for<0, 3>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            double a = v[r];
+            J.mac<J_DT>(a, v[3 + r]);
+            o[r] = a;
+            double b = v[3 + r];
+            J.mac<J_A + 3 * r>(b, v[6]); J.mac<J_A + 3 * r + 1>(b, v[7]); J.mac<J_A + 3 * r + 2>(b, v[8]);
+            o[3 + r] = b;
+            double c = 0.0;
+            J.mac<J_TH + 3 * r>(c, v[6]); J.mac<J_TH + 3 * r + 1>(c, v[7]); J.mac<J_TH + 3 * r + 2>(c, v[8]);
+            o[6 + r] = c;
+        });
+        double o15 = v[15], o16 = v[16];
+        J.mac<J_DT>(o15, v[16]);
+        J.mac<J_DT>(o16, v[17]);
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) lds_store1(dst + k, o[k]);
+#pragma unroll
+            for (int k = 9; k < 15; ++k) lds_store1(dst + k, v[k]);
+            lds_store1(dst + 15, o15);
+            lds_store1(dst + 16, o16);
+            lds_store1(dst + 17, v[17]);
+        }
+    }
+    {
+        double o[3];
+        static_for<0, 3>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            double u = v[16 + r];
+            J.mac<J_DT>(u, v[3 + r]);
+            J.mac<J_BM + 3 * r>(u, v[6]); J.mac<J_BM + 3 * r + 1>(u, v[7]); J.mac<J_BM + 3 * r + 2>(u, v[8]);
+            static_for<0, 6>([&](auto K) { J.mac<J_CM + 6 * r + decltype(K)::value>(u, v[9 + decltype(K)::value]); });
+            o[r] = u;
+        });
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lds_store1(dst + 18 + r, o[r]);
+        }
+    }
+    {
+        double o[3];
+        static_for<0, 3>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            double w = 0.0;
+            J.mac<J_DM + 4 * r + 3>(w, v[15]);
+            J.mac<J_DM + 4 * r>(w, v[9]); J.mac<J_DM + 4 * r + 1>(w, v[10]); J.mac<J_DM + 4 * r + 2>(w, v[11]);
+            J.mac<J_EM + 3 * r>(w, v[19]); J.mac<J_EM + 3 * r + 1>(w, v[20]); J.mac<J_EM + 3 * r + 2>(w, v[21]);
+            if (r == 1) w += v[22];
+            if (r == 2) w += v[23];
+            o[r] = w;
+        });
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) lds_store1(dst + 21 + r, o[r]);
+        }
+    }
+}
+__device__ __forceinline__ void fx_apply_col_dpp(const JRegs& J, const double* col, double (&o)[24]) {
+    double u[3], w[3];
+    {   // inputs 0..8
+        double c[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k] = lds_load1(col + k * PS);
+        static_for<0, 3>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            double x = 0.0;                 // dt c[3+r], used twice (see fx_apply_store_dpp)
+            J.mac<J_DT>(x, c[3 + r]);
+            o[r] = c[r] + x;
+            double b = c[3 + r];
+            J.mac<J_A + 3 * r>(b, c[6]); J.mac<J_A + 3 * r + 1>(b, c[7]); J.mac<J_A + 3 * r + 2>(b, c[8]);
+            o[3 + r] = b;
+            double t = 0.0;
+            J.mac<J_TH + 3 * r>(t, c[6]); J.mac<J_TH + 3 * r + 1>(t, c[7]); J.mac<J_TH + 3 * r + 2>(t, c[8]);
+            o[6 + r] = t;
+            J.mac<J_BM + 3 * r>(x, c[6]); J.mac<J_BM + 3 * r + 1>(x, c[7]); J.mac<J_BM + 3 * r + 2>(x, c[8]);
+            u[r] = x;
+        });
+    }
+    {   // inputs 9..17
+        double c[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c[k] = lds_load1(col + (9 + k) * PS);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[9 + k] = c[k];
+        double o15 = c[6], o16 = c[7];
+        J.mac<J_DT>(o15, c[7]);
+        J.mac<J_DT>(o16, c[8]);
+        o[15] = o15;
+        o[16] = o16;
+        o[17] = c[8];
+        u[0] += c[7];                       // c[16 + r], r = 0, 1 (r = 2 is input 18)
+        u[1] += c[8];
+        static_for<0, 3>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            static_for<0, 6>([&](auto K) { J.mac<J_CM + 6 * r + decltype(K)::value>(u[r], c[decltype(K)::value]); });
+            double y = 0.0;
+            J.mac<J_DM + 4 * r + 3>(y, c[6]);
+            J.mac<J_DM + 4 * r>(y, c[0]); J.mac<J_DM + 4 * r + 1>(y, c[1]); J.mac<J_DM + 4 * r + 2>(y, c[2]);
+            w[r] = y;
+        });
+    }
+    {   // inputs 18..23
+        double c[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c[k] = lds_load1(col + (18 + k) * PS);
+        u[2] += c[0];
+        static_for<0, 3>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            J.mac<J_EM + 3 * r>(w[r], c[1]); J.mac<J_EM + 3 * r + 1>(w[r], c[2]); J.mac<J_EM + 3 * r + 2>(w[r], c[3]);
+        });
+        w[1] += c[4];
+        w[2] += c[5];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o[18 + r] = u[r]; o[21 + r] = w[r]; }
+}
+// float overloads: never instantiated on a taken path (the fp32 kernels keep the LDS exchange)
+__device__ __forceinline__ void fx_apply_store_dpp(const JRegs&, const float (&)[24], float*, bool) {}
+__device__ __forceinline__ void fx_apply_col_dpp(const JRegs&, const float*, float (&)[24]) {}
 __device__ __forceinline__ void spread_rows(float, float&, float&) {}
 template <int LANE, bool FIRST = false>
 __device__ __forceinline__ void dpp_fmac(float&, float, float) {}
@@ -1456,13 +1605,21 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // LPI: lanes per instance.  32: one wavefront hosts two instances (8 of every 32 lanes idle, no barrier
 // needed: a block is one wave).  24: a block of three wavefronts hosts eight instances, every lane owns a
 // row; instances straddle wavefronts, so the exchanges are separated by real block barriers.
-template <typename T, bool PIN = false, int LPI = 32>
-__global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
+// SLIM (fp64, 32 lanes per instance, shared noise model, no gyro block in Q -- the headline configuration):
+// with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
+// kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
+// VGPRs: four wavefronts per SIMD, sixteen per CU.
+template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false>
+__global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     using namespace rowk;
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
+    static_assert(!SLIM || (LPI == 32 && !PIN && sizeof(T) == 8), "SLIM: fp64, 32 lanes, shared noise model");
     constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
     constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
-    constexpr int REGION = PIN ? R_REGION_PIN : R_REGION;
+    constexpr int REGION = SLIM ? 640 : PIN ? R_REGION_PIN : R_REGION;
+    constexpr int R_C = SLIM ? 600 : rowk::R_C;
+    constexpr int R_RES = SLIM ? 624 : rowk::R_RES;
+    constexpr int R_J = SLIM ? 0 : rowk::R_J;      // (SLIM: never addressed)
     __shared__ __attribute__((aligned(16))) T smem[G * REGION];
 
     const int lane = threadIdx.x;
@@ -1505,11 +1662,21 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
         RES.x = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                \
         if (PIN) RES.y = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + (lj_ < 24 ? lj_ : 23)]; \
     }
+    // fp64 with 32 lanes per instance: the record stays in the registers it was fetched into and is
+    // handed to the Fx applications as DPP operands (JRegs); it is copied to LDS only for the gyro
+    // block of Q (tune mode), whose N6 rows noise_rows() reads from there
+    constexpr bool DPPJ = LPI == 32 && sizeof(T) == 8;
+    JRegs Jr;
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
-        _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w_ = kRowsTables.jdst[TV][lig][k];                                           \
-            sJ[w_ < jlast_lds ? w_ : jlast_lds] = SRC[k];                                          \
+        if constexpr (DPPJ) {                                                                      \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) spread_rows(SRC[k], Jr.X[k], Jr.Y[k]);   \
+        }                                                                                          \
+        if (!SLIM && (!DPPJ || prm.q_gyro)) {                                                      \
+            _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                       \
+                const int w_ = kRowsTables.jdst[TV][lig][k];                                       \
+                sJ[w_ < jlast_lds ? w_ : jlast_lds] = SRC[k];                                      \
+            }                                                                                      \
         }                                                                                          \
         sR[lig & 7] = RES.x;            /* (several lanes, same value) */                          \
         if (PIN) sR[8 + (lig < 24 ? lig : 23)] = RES.y;                                            \
@@ -1549,10 +1716,12 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, ROWS_WAVES) void eskf_cov_row
     // one predict on the row-resident P with the Jacobian record that sits in LDS
 #define ESKF_PREDICT_ROWS()                                                                        \
     {                                                                                              \
-        fx_apply_store(sJ, p, sB + row * PS, active);   /* column `row` of Fx P = row `row` of W = P Fx^T */ \
+        if constexpr (DPPJ) fx_apply_store_dpp(Jr, p, sB + row * PS, active);                      \
+        else fx_apply_store(sJ, p, sB + row * PS, active);   /* column `row` of Fx P = row `row` of W = P Fx^T */ \
         group_sync();                                                                              \
-        fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */          \
-        noise_rows<T, PIN>(prm, sJ, sN, row, p);                                                               \
+        if constexpr (DPPJ) fx_apply_col_dpp(Jr, sB + row, p);                                     \
+        else fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */     \
+        noise_rows<T, PIN, !SLIM>(prm, sJ, sN, row, p);                                            \
         group_sync();                                                                              \
     }
     const bool valid = slot < nB;           // tail: recompute the last instance, write nothing
@@ -1993,6 +2162,12 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     constexpr int G = LPI == 32 ? 2 : 8;                    // instances per block
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
     const int64_t blocks = (a.B + G - 1) / G;
+    if constexpr (sizeof(T) == 8 && LPI == 32 && !PIN) {
+        if (!prm.q_gyro) {      // the headline configuration: the four-waves-per-SIMD build of the same kernel
+            hipLaunchKernelGGL((eskf_cov_rows_kernel<T, false, 32, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, LPI>), dim3((unsigned)blocks), dim3(LPI == 32 ? 64 : 192), 0, stream, a, prm);
     return hipGetLastError();
 }
