@@ -1562,6 +1562,7 @@ struct RowsTables {                  // [v]: lane layout v = 0: 32 lanes per ins
     int pos[2][32][16];
     int gat[24][24];
     int gatp[24][24];    // packed-record word of P[row][j] (= of P[max][min])
+    int gatp8[24][24];   // ... as a byte offset (fp64)
     int jsrc[2][32][4];  // Jacobian record: the record words lane lig moves (clamped to the record) ...
     int jdst[2][32][4];  // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
 };
@@ -1591,6 +1592,7 @@ constexpr RowsTables make_rows_tables() {
             t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
             const int hi = j <= r ? r : j, lo = j <= r ? j : r;
             t.gatp[r][j] = hi < 12 ? (25 * hi + lo) : (25 * (23 - hi) + (23 - hi) + 1 + lo);
+            t.gatp8[r][j] = 8 * (hi < 12 ? (25 * hi + lo) : (25 * (23 - hi) + (23 - hi) + 1 + lo));
         }
     return t;
 }
@@ -1690,9 +1692,15 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     {                                                                                              \
         const T* gP_ = reinterpret_cast<const T*>(a.P) + (int64_t)inst * 300;                      \
         if (sizeof(T) == 8) {                                                                      \
-            int gat_[24];                                                                          \
-            _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gatp[row][j];     \
-            _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = gP_[gat_[j]];                    \
+            /* wave-uniform base (scalar registers) + an unsigned 32-bit lane offset: one address  \
+               instruction per load instead of a sign extension and a 64-bit add */                \
+            const int i0_ = (int)blockIdx.x * G;                                                   \
+            const T* gPw_ = reinterpret_cast<const T*>(a.P) + (int64_t)i0_ * 300;                  \
+            const unsigned io_ = (unsigned)(inst - i0_) * (300u * 8u);                             \
+            unsigned gat_[24];                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = (unsigned)kRowsTables.gatp8[row][j]; \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j)                                         \
+                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)(io_ + gat_[j])); \
             group_sync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
         } else {                                                                                   \
             const T2* gP2_ = reinterpret_cast<const T2*>(gP_);                                     \
