@@ -1607,7 +1607,7 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // LPI: lanes per instance.  32: one wavefront hosts two instances (8 of every 32 lanes idle, no barrier
 // needed: a block is one wave).  24: a block of three wavefronts hosts eight instances, every lane owns a
 // row; instances straddle wavefronts, so the exchanges are separated by real block barriers.
-// SLIM (fp64, 32 lanes per instance, shared noise model, no gyro block in Q -- the headline configuration):
+// SLIM (fp64, 32 lanes per instance, no gyro block in Q -- the headline configuration and the tuning populations):
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
@@ -1615,10 +1615,11 @@ template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false>
 __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     using namespace rowk;
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
-    static_assert(!SLIM || (LPI == 32 && !PIN && sizeof(T) == 8), "SLIM: fp64, 32 lanes, shared noise model");
+    static_assert(!SLIM || (LPI == 32 && sizeof(T) == 8), "SLIM: fp64, 32 lanes per instance");
     constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
     constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
-    constexpr int REGION = SLIM ? 640 : PIN ? R_REGION_PIN : R_REGION;
+    // (with per-instance noise the 24-word noise record follows the residual: 664 words, 15 wavefronts per CU)
+    constexpr int REGION = SLIM ? (PIN ? 664 : 640) : PIN ? R_REGION_PIN : R_REGION;
     constexpr int R_C = SLIM ? 600 : rowk::R_C;
     constexpr int R_RES = SLIM ? 624 : rowk::R_RES;
     constexpr int R_J = SLIM ? 0 : rowk::R_J;      // (SLIM: never addressed)
@@ -2170,9 +2171,9 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     constexpr int G = LPI == 32 ? 2 : 8;                    // instances per block
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
     const int64_t blocks = (a.B + G - 1) / G;
-    if constexpr (sizeof(T) == 8 && LPI == 32 && !PIN) {
-        if (!prm.q_gyro) {      // the headline configuration: the four-waves-per-SIMD build of the same kernel
-            hipLaunchKernelGGL((eskf_cov_rows_kernel<T, false, 32, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+    if constexpr (sizeof(T) == 8 && LPI == 32) {
+        if (!prm.q_gyro) {      // no gyro block in Q (the normal case): the four-waves-per-SIMD build of the same kernel
+            hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, 32, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
             return hipGetLastError();
         }
     }
