@@ -1401,6 +1401,24 @@ __device__ __forceinline__ double dpp_bcast(double src) {
     asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
     return r;
 }
+// fp32: the same three primitives on one dword
+__device__ __forceinline__ void spread_rows(float v, float& X, float& Y) {
+    const int w = __float_as_int(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    X = __int_as_float(a[0]);
+    Y = __int_as_float(a[1]);
+    asm("s_nop 1" : "+v"(X), "+v"(Y));
+}
+template <int LANE, bool FIRST = false>
+__device__ __forceinline__ void dpp_fmac(float& acc, float src, float mul) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+}
+template <int LANE>
+__device__ __forceinline__ float dpp_bcast(float src) {
+    float r;
+    asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
+    return r;
+}
 template <int J0, int J1, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (J0 < J1) {
@@ -1412,35 +1430,37 @@ __device__ __forceinline__ void static_for(F&& f) {
 // The Jacobian record of an instance spread over its 32 lanes (lane l holds words l, 32+l, 64+l -- the
 // registers the record is fetched into) and made reachable as DPP operands: X[k] / Y[k] carry the k-th
 // word of the lanes of the first / second 16-lane row in both rows.
+template <typename T>
 struct JRegs {
-    double X[3], Y[3];
+    T X[3], Y[3];
     // acc += J[W] * v
     template <int W, bool FIRST = false>
-    __device__ __forceinline__ void mac(double& acc, double v) const {
+    __device__ __forceinline__ void mac(T& acc, T v) const {
         constexpr int k = W >> 5, l = W & 31;
         dpp_fmac<(l & 15), FIRST>(acc, l < 16 ? X[k] : Y[k], v);
     }
 };
 // dst[0:24] = Fx v and o = Fx c: the operations of fx_apply_store / fx_apply_col in the same order (the two
 // lane layouts give the same bits), with the Jacobian entries as DPP operands instead of LDS reads
-__device__ __forceinline__ void fx_apply_store_dpp(const JRegs& J, const double (&v)[24], double* dst, bool active) {
+template <typename T>
+__device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&v)[24], T* dst, bool active) {
     {
-        double o[9];
+        T o[9];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            double a = v[r];
-            J.mac<J_DT>(a, v[3 + r]);
+            T a = v[r];
+            J.template mac<J_DT>(a, v[3 + r]);
             o[r] = a;
-            double b = v[3 + r];
-            J.mac<J_A + 3 * r>(b, v[6]); J.mac<J_A + 3 * r + 1>(b, v[7]); J.mac<J_A + 3 * r + 2>(b, v[8]);
+            T b = v[3 + r];
+            J.template mac<J_A + 3 * r>(b, v[6]); J.template mac<J_A + 3 * r + 1>(b, v[7]); J.template mac<J_A + 3 * r + 2>(b, v[8]);
             o[3 + r] = b;
-            double c = 0.0;
-            J.mac<J_TH + 3 * r>(c, v[6]); J.mac<J_TH + 3 * r + 1>(c, v[7]); J.mac<J_TH + 3 * r + 2>(c, v[8]);
+            T c = T(0);
+            J.template mac<J_TH + 3 * r>(c, v[6]); J.template mac<J_TH + 3 * r + 1>(c, v[7]); J.template mac<J_TH + 3 * r + 2>(c, v[8]);
             o[6 + r] = c;
         });
-        double o15 = v[15], o16 = v[16];
-        J.mac<J_DT>(o15, v[16]);
-        J.mac<J_DT>(o16, v[17]);
+        T o15 = v[15], o16 = v[16];
+        J.template mac<J_DT>(o15, v[16]);
+        J.template mac<J_DT>(o16, v[17]);
         if (active) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) lds_store1(dst + k, o[k]);
@@ -1452,13 +1472,13 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs& J, const double 
         }
     }
     {
-        double o[3];
+        T o[3];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            double u = v[16 + r];
-            J.mac<J_DT>(u, v[3 + r]);
-            J.mac<J_BM + 3 * r>(u, v[6]); J.mac<J_BM + 3 * r + 1>(u, v[7]); J.mac<J_BM + 3 * r + 2>(u, v[8]);
-            static_for<0, 6>([&](auto K) { J.mac<J_CM + 6 * r + decltype(K)::value>(u, v[9 + decltype(K)::value]); });
+            T u = v[16 + r];
+            J.template mac<J_DT>(u, v[3 + r]);
+            J.template mac<J_BM + 3 * r>(u, v[6]); J.template mac<J_BM + 3 * r + 1>(u, v[7]); J.template mac<J_BM + 3 * r + 2>(u, v[8]);
+            static_for<0, 6>([&](auto K) { J.template mac<J_CM + 6 * r + decltype(K)::value>(u, v[9 + decltype(K)::value]); });
             o[r] = u;
         });
         if (active) {
@@ -1467,13 +1487,13 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs& J, const double 
         }
     }
     {
-        double o[3];
+        T o[3];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            double w = 0.0;
-            J.mac<J_DM + 4 * r + 3>(w, v[15]);
-            J.mac<J_DM + 4 * r>(w, v[9]); J.mac<J_DM + 4 * r + 1>(w, v[10]); J.mac<J_DM + 4 * r + 2>(w, v[11]);
-            J.mac<J_EM + 3 * r>(w, v[19]); J.mac<J_EM + 3 * r + 1>(w, v[20]); J.mac<J_EM + 3 * r + 2>(w, v[21]);
+            T w = T(0);
+            J.template mac<J_DM + 4 * r + 3>(w, v[15]);
+            J.template mac<J_DM + 4 * r>(w, v[9]); J.template mac<J_DM + 4 * r + 1>(w, v[10]); J.template mac<J_DM + 4 * r + 2>(w, v[11]);
+            J.template mac<J_EM + 3 * r>(w, v[19]); J.template mac<J_EM + 3 * r + 1>(w, v[20]); J.template mac<J_EM + 3 * r + 2>(w, v[21]);
             if (r == 1) w += v[22];
             if (r == 2) w += v[23];
             o[r] = w;
@@ -1484,36 +1504,37 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs& J, const double 
         }
     }
 }
-__device__ __forceinline__ void fx_apply_col_dpp(const JRegs& J, const double* col, double (&o)[24]) {
-    double u[3], w[3];
+template <typename T>
+__device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col, T (&o)[24]) {
+    T u[3], w[3];
     {   // inputs 0..8
-        double c[9];
+        T c[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) c[k] = lds_load1(col + k * PS);
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            double x = 0.0;                 // dt c[3+r], used twice (see fx_apply_store_dpp)
-            J.mac<J_DT>(x, c[3 + r]);
+            T x = T(0);                 // dt c[3+r], used twice (see fx_apply_store_dpp)
+            J.template mac<J_DT>(x, c[3 + r]);
             o[r] = c[r] + x;
-            double b = c[3 + r];
-            J.mac<J_A + 3 * r>(b, c[6]); J.mac<J_A + 3 * r + 1>(b, c[7]); J.mac<J_A + 3 * r + 2>(b, c[8]);
+            T b = c[3 + r];
+            J.template mac<J_A + 3 * r>(b, c[6]); J.template mac<J_A + 3 * r + 1>(b, c[7]); J.template mac<J_A + 3 * r + 2>(b, c[8]);
             o[3 + r] = b;
-            double t = 0.0;
-            J.mac<J_TH + 3 * r>(t, c[6]); J.mac<J_TH + 3 * r + 1>(t, c[7]); J.mac<J_TH + 3 * r + 2>(t, c[8]);
+            T t = T(0);
+            J.template mac<J_TH + 3 * r>(t, c[6]); J.template mac<J_TH + 3 * r + 1>(t, c[7]); J.template mac<J_TH + 3 * r + 2>(t, c[8]);
             o[6 + r] = t;
-            J.mac<J_BM + 3 * r>(x, c[6]); J.mac<J_BM + 3 * r + 1>(x, c[7]); J.mac<J_BM + 3 * r + 2>(x, c[8]);
+            J.template mac<J_BM + 3 * r>(x, c[6]); J.template mac<J_BM + 3 * r + 1>(x, c[7]); J.template mac<J_BM + 3 * r + 2>(x, c[8]);
             u[r] = x;
         });
     }
     {   // inputs 9..17
-        double c[9];
+        T c[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) c[k] = lds_load1(col + (9 + k) * PS);
 #pragma unroll
         for (int k = 0; k < 6; ++k) o[9 + k] = c[k];
-        double o15 = c[6], o16 = c[7];
-        J.mac<J_DT>(o15, c[7]);
-        J.mac<J_DT>(o16, c[8]);
+        T o15 = c[6], o16 = c[7];
+        J.template mac<J_DT>(o15, c[7]);
+        J.template mac<J_DT>(o16, c[8]);
         o[15] = o15;
         o[16] = o16;
         o[17] = c[8];
@@ -1521,21 +1542,21 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs& J, const double* c
         u[1] += c[8];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            static_for<0, 6>([&](auto K) { J.mac<J_CM + 6 * r + decltype(K)::value>(u[r], c[decltype(K)::value]); });
-            double y = 0.0;
-            J.mac<J_DM + 4 * r + 3>(y, c[6]);
-            J.mac<J_DM + 4 * r>(y, c[0]); J.mac<J_DM + 4 * r + 1>(y, c[1]); J.mac<J_DM + 4 * r + 2>(y, c[2]);
+            static_for<0, 6>([&](auto K) { J.template mac<J_CM + 6 * r + decltype(K)::value>(u[r], c[decltype(K)::value]); });
+            T y = T(0);
+            J.template mac<J_DM + 4 * r + 3>(y, c[6]);
+            J.template mac<J_DM + 4 * r>(y, c[0]); J.template mac<J_DM + 4 * r + 1>(y, c[1]); J.template mac<J_DM + 4 * r + 2>(y, c[2]);
             w[r] = y;
         });
     }
     {   // inputs 18..23
-        double c[6];
+        T c[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c[k] = lds_load1(col + (18 + k) * PS);
         u[2] += c[0];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            J.mac<J_EM + 3 * r>(w[r], c[1]); J.mac<J_EM + 3 * r + 1>(w[r], c[2]); J.mac<J_EM + 3 * r + 2>(w[r], c[3]);
+            J.template mac<J_EM + 3 * r>(w[r], c[1]); J.template mac<J_EM + 3 * r + 1>(w[r], c[2]); J.template mac<J_EM + 3 * r + 2>(w[r], c[3]);
         });
         w[1] += c[4];
         w[2] += c[5];
@@ -1543,14 +1564,6 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs& J, const double* c
 #pragma unroll
     for (int r = 0; r < 3; ++r) { o[18 + r] = u[r]; o[21 + r] = w[r]; }
 }
-// float overloads: never instantiated on a taken path (the fp32 kernels keep the LDS exchange)
-__device__ __forceinline__ void fx_apply_store_dpp(const JRegs&, const float (&)[24], float*, bool) {}
-__device__ __forceinline__ void fx_apply_col_dpp(const JRegs&, const float*, float (&)[24]) {}
-__device__ __forceinline__ void spread_rows(float, float&, float&) {}
-template <int LANE, bool FIRST = false>
-__device__ __forceinline__ void dpp_fmac(float&, float, float) {}
-template <int LANE>
-__device__ __forceinline__ float dpp_bcast(float v) { return v; }
 }  // namespace rowk
 
 // Index tables of the row-resident kernel, computed at compile time and read from device memory (a few
@@ -1615,7 +1628,7 @@ template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false>
 __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     using namespace rowk;
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
-    static_assert(!SLIM || (LPI == 32 && sizeof(T) == 8), "SLIM: fp64, 32 lanes per instance");
+    static_assert(!SLIM || LPI == 32, "SLIM: 32 lanes per instance");
     constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
     constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
     // (with per-instance noise the 24-word noise record follows the residual: 664 words, 15 wavefronts per CU)
@@ -1668,8 +1681,8 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     // fp64 with 32 lanes per instance: the record stays in the registers it was fetched into and is
     // handed to the Fx applications as DPP operands (JRegs); it is copied to LDS only for the gyro
     // block of Q (tune mode), whose N6 rows noise_rows() reads from there
-    constexpr bool DPPJ = LPI == 32 && sizeof(T) == 8;
-    JRegs Jr;
+    constexpr bool DPPJ = LPI == 32;
+    JRegs<T> Jr;
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
         if constexpr (DPPJ) {                                                                      \
@@ -1777,7 +1790,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
         int napplied = 0;
         // fp64, 32 lanes per instance: the column every lane needs is handed around as DPP operands
         // (no LDS read-back, no barrier); the LDS copy is only written, for the take-back below
-        constexpr bool DPPU = LPI == 32 && sizeof(T) == 8;
+        constexpr bool DPPU = LPI == 32;
         if constexpr (DPPU) {
             static_for<0, 7>([&](auto M) {
                 constexpr int m = decltype(M)::value;
@@ -2171,7 +2184,7 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     constexpr int G = LPI == 32 ? 2 : 8;                    // instances per block
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
     const int64_t blocks = (a.B + G - 1) / G;
-    if constexpr (sizeof(T) == 8 && LPI == 32) {
+    if constexpr (LPI == 32) {
         if (!prm.q_gyro) {      // no gyro block in Q (the normal case): the four-waves-per-SIMD build of the same kernel
             hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, 32, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
             return hipGetLastError();
