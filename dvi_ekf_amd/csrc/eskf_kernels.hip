@@ -1368,7 +1368,7 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
                  : : "memory");
 }
 
-// ---- cross-lane broadcast without LDS (fp64, 32 lanes per instance) -------------------------------
+// ---- cross-lane broadcast without LDS (32 lanes per instance; fp64 shown, fp32 below) --------------
 // An instance occupies two 16-lane DPP rows: rows 0..15 of P in the first, rows 16..23 (+ 8 shadow
 // lanes) in the second.  `row_newbcast:n` feeds lane n of the reader's own 16-lane row to every lane
 // of that row as a source operand of a DP-rate instruction at no extra cost, so a value that every lane
@@ -1611,7 +1611,7 @@ constexpr RowsTables make_rows_tables() {
 }
 __device__ const RowsTables kRowsTables = make_rows_tables();
 
-// waves per SIMD the row-resident kernel is built for: 3 (<= 168 VGPRs; it needs 162)
+// waves per SIMD the general build of the row-resident kernel is made for: 3 (<= 168 VGPRs); SLIM: 4
 #ifndef ROWS_WAVES
 #define ROWS_WAVES 3
 #endif
@@ -1620,7 +1620,8 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // LPI: lanes per instance.  32: one wavefront hosts two instances (8 of every 32 lanes idle, no barrier
 // needed: a block is one wave).  24: a block of three wavefronts hosts eight instances, every lane owns a
 // row; instances straddle wavefronts, so the exchanges are separated by real block barriers.
-// SLIM (fp64, 32 lanes per instance, no gyro block in Q -- the headline configuration and the tuning populations):
+// SLIM (32 lanes per instance, no gyro block in Q -- the headline configuration and the tuning populations;
+// sizes below are the fp64 ones):
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
@@ -1678,7 +1679,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
         RES.x = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                \
         if (PIN) RES.y = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + (lj_ < 24 ? lj_ : 23)]; \
     }
-    // fp64 with 32 lanes per instance: the record stays in the registers it was fetched into and is
+    // 32 lanes per instance: the record stays in the registers it was fetched into and is
     // handed to the Fx applications as DPP operands (JRegs); it is copied to LDS only for the gyro
     // block of Q (tune mode), whose N6 rows noise_rows() reads from there
     constexpr bool DPPJ = LPI == 32;
@@ -1788,7 +1789,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 #pragma unroll
         for (int m = 0; m < 7; ++m) E[m] = T(0);
         int napplied = 0;
-        // fp64, 32 lanes per instance: the column every lane needs is handed around as DPP operands
+        // 32 lanes per instance: the column every lane needs is handed around as DPP operands
         // (no LDS read-back, no barrier); the LDS copy is only written, for the take-back below
         constexpr bool DPPU = LPI == 32;
         if constexpr (DPPU) {
