@@ -1375,8 +1375,9 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 // of the instance holds for its own row -- a column of P -- reaches all rows as `v_fmac_f64_dpp`
 // operands once both 16-lane rows carry it: spread_rows() makes X = (first row's values in both rows)
 // and Y = (second row's values in both rows) with one v_permlane16_swap per dword.
-// (Checked on gfx950 with variants of tools/-style micro-kernels: row_newbcast semantics, the swap's
-//  row pairing, and v_fmac_f64_dpp issuing at the rate of v_fmac_f64.)
+// (Checked on gfx950 with tools/dpp_micro.hip and tools/dpp_semantics.hip: row_newbcast semantics, the
+//  swap's row pairing -- and that it needs its wait states --, v_fmac_f64_dpp issuing at the rate of
+//  v_fmac_f64.)
 __device__ __forceinline__ void spread_rows(double v, double& X, double& Y) {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);

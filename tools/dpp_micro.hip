@@ -1,3 +1,4 @@
+// build & run on the GPU box: hipcc -O3 --offload-arch=gfx950 tools/dpp_micro.hip -o /tmp/dpp_micro && /tmp/dpp_micro
 // micro-checks for the DPP-broadcast update: semantics of row_newbcast on f64, permlane16_swap, and issue rate
 #include <hip/hip_runtime.h>
 #include <cstdio>

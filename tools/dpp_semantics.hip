@@ -1,3 +1,5 @@
+// lane patterns of v_permlane16_swap / v_permlane32_swap (with the wait states inline assembly has to provide itself)
+// build & run on the GPU box: hipcc -O3 --offload-arch=gfx950 tools/dpp_semantics.hip -o /tmp/dpp_sem && /tmp/dpp_sem
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void sem(int* outi, int nop) {
