@@ -146,10 +146,22 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("DVI_BENCH_BACKEND", "nccl") == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        # RCCL prints a version banner on STDOUT when a communicator is created; stdout of this
+        # program is the one JSON line, so the file descriptor points at stderr meanwhile
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if os.environ.get("DVI_BENCH_BACKEND", "nccl") == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from dvi_ekf_amd.workloads import monte_carlo_pairs
     B, H, K, W = args.batch, args.horizon, args.steps, args.warmup
