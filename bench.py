@@ -124,6 +124,9 @@ def main():
     ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
     ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident; 64/32/24/16/12/8 = LDS-image kernel with that many lanes per instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--restore-copy", action="store_true",
+                    help="restart a horizon by copying the snapshot into the filter (176 MB device-to-device) and stepping in "
+                         "place, instead of letting the horizon's first step read the snapshot (dvi_eskf_step_from)")
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--per-instance-noise", action="store_true",
                     help="diagnostic: every instance carries its own (identical) noise record -- the tuning-population path")
@@ -178,11 +181,17 @@ def main():
     snap = f.clone()
     status = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    def step(k):
-        i = k % H
+    def pair(i):
+        """pair-step i of the horizon; the first one starts from the snapshot"""
+        if i == 0 and not args.restore_copy:
+            f.step_from(snap, wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+            return
         if i == 0:
             f.copy_state_from(snap)
         f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+
+    def step(k):
+        pair(k % H)
 
     def barrier():
         if dist is not None:
@@ -237,14 +246,15 @@ def main():
             k += H
     while k < K:                                             # remainder (or everything, without a graph)
         i = k % H
-        if i == 0:
-            f.copy_state_from(snap)
         if args.mode == "pair":
-            f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
-        elif args.mode == "predict":
-            f.predict(wl.dt[i], wl.om[i], wl.acc[i])
+            pair(i)
         else:
-            f.update(wl.pos[i], wl.quat[i], wl.notch[i])
+            if i == 0:
+                f.copy_state_from(snap)
+            if args.mode == "predict":
+                f.predict(wl.dt[i], wl.om[i], wl.acc[i])
+            else:
+                f.update(wl.pos[i], wl.quat[i], wl.notch[i])
         k += 1
     dofs = f.calibration()
     if dist is not None:
@@ -258,11 +268,14 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for k in range(n_ev):
         i = k % H
-        if i == 0:
+        if i == 0 and (args.mode != "pair" or args.restore_copy):
             f.copy_state_from(snap)
         ev[k][0].record()
         if args.mode == "pair":
-            f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+            if i == 0 and not args.restore_copy:
+                f.step_from(snap, wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
+            else:
+                f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
         elif args.mode == "predict":
             f.predict(wl.dt[i], wl.om[i], wl.acc[i])
         else:
@@ -310,7 +323,10 @@ def main():
                 "workload": "BASELINE config #2/#4: Monte-Carlo batch on mandala0_mono, 1:1 predict+update "
                             "pairs (dt=1.0), unfrozen DOFs, per-instance IMU/camera noise and perturbed ICs",
                 "batch_per_gpu": B, "global_batch": B * world, "horizon_between_state_restores": H,
-                "state_restore_in_timed_region": True, "covariance_kernel": "row-resident" if (args.lanes or 1) == 1 else "lds-image, %d lanes/instance" % args.lanes,
+                "state_restore_in_timed_region": True,
+                "state_restore": "device-to-device copy of the snapshot" if args.restore_copy else
+                                 "the first pair-step of a horizon reads the snapshot handle (dvi_eskf_step_from)",
+                "covariance_kernel": "row-resident" if (args.lanes or 1) == 1 else "lds-image, %d lanes/instance" % args.lanes,
                 "hip_graph": graph is not None,
                 "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
             },

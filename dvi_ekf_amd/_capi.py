@@ -55,6 +55,7 @@ SIGNATURES = {
     "dvi_eskf_update": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_step": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_epoch": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "dvi_eskf_step_from": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_run_epochs": (_i, [_vp, C.POINTER(Schedule), _vp]),
     "dvi_eskf_get_calibration": (_i, [_vp, _vp, _vp]),
     "dvi_eskf_gather_calibration": (_i, [_vp, _vp, _vp, _vp]),

@@ -218,6 +218,24 @@ class BatchedESKF:
                                            _ptr(tn), per, _ptr(K), _ptr(status), self._stream()), "dvi_eskf_step")
         return status, K
 
+    def step_from(self, src: "BatchedESKF", dt, om, acc, pos, quat, notch, want_gain: bool = False,
+                  status: Optional[torch.Tensor] = None):
+        """``self <- step(src)``: one predict + one update that READS the state of ``src`` (left untouched)
+        and writes the result here -- a restart from a snapshot without copying it first."""
+        tdt, pdt = self._dev(dt, ())
+        tom, pim = self._dev(om, (3,))
+        tac, pa = self._dev(acc, (3,))
+        if pim != pa:
+            raise ValueError("om and acc must both be per-instance or both broadcast")
+        tp, tq, tn, per = self._meas(pos, quat, notch)
+        K = torch.empty((self.batch, 24, 7), dtype=self.dtype, device=self.device) if want_gain else None
+        if status is None:
+            status = torch.zeros(self.batch, dtype=torch.int32, device=self.device)
+        _capi.check(self.lib.dvi_eskf_step_from(self._h, src._h, 1, _ptr(tdt), pdt, _ptr(tom), _ptr(tac), pim, _ptr(tp),
+                                                _ptr(tq), _ptr(tn), per, _ptr(K), _ptr(status), self._stream()),
+                    "dvi_eskf_step_from")
+        return status, K
+
     def run_epochs(self, n_pred, dt, om, acc, pos, quat, notch, t_log=None):
         """A whole run (Filter.run, Filter.py:144-168) enqueued by one call: epoch e = n_pred[e]
         predicts + the update with measurement e.  dt [total] | [total,B]; om/acc [total,3] |

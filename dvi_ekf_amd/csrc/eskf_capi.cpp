@@ -96,6 +96,7 @@ eskf::StepArgs base_args(const dvi_eskf* h) {
     eskf::StepArgs a;
     std::memset(&a, 0, sizeof a);
     a.P = h->d_P; a.xs = h->d_x;
+    a.P_src = h->d_P; a.xs_src = h->d_x;
     a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status; a.noise = h->d_noise;
     a.B = h->B;
     a.rounds = 1;
@@ -113,8 +114,10 @@ int flush_pending(dvi_eskf* h, hipStream_t stream) {
 
 int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_pi, const void* om, const void* acc,
                 int imu_pi, const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out,
-                int32_t* status, void* stream) {
+                int32_t* status, void* stream, dvi_eskf* src = nullptr) {
     if (!h) return DVI_ESKF_EINVAL;
+    if (src == h) src = nullptr;
+    if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
     if (n_pred < 0) return DVI_ESKF_EINVAL;
     if (n_pred > 0 && (!dt || !om || !acc)) return DVI_ESKF_EINVAL;
     if (do_update && (!pos || !quat || !notch)) return DVI_ESKF_EINVAL;
@@ -133,6 +136,12 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     a.imu_stride = imu_pi ? 1 : 0;
     a.meas_stride = meas_pi ? 1 : 0;
     a.apply_pending = h->pending ? 1 : 0;
+    if (src) {      // read the other handle's (flushed) state; whatever this handle held is replaced
+        if (flush_pending(src, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+        a.P_src = src->d_P;
+        a.xs_src = src->d_x;
+        a.apply_pending = 0;
+    }
     hipError_t e = eskf::launch_step(h->dtype, h->lpi, a, h->hp, (hipStream_t)stream);
     if (e != hipSuccess) return DVI_ESKF_EHIP;
     h->pending = do_update != 0;      // this update's injection is applied by the next step or a flush
@@ -340,6 +349,13 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_pi, const voi
                    const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out, int32_t* status,
                    void* stream) {
     return step_common(h, n_pred, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream);
+}
+
+int dvi_eskf_step_from(dvi_eskf* h, dvi_eskf* src, int n_pred, const void* dt, int dt_pi, const void* om,
+                       const void* acc, int imu_pi, const void* pos, const void* quat, const void* notch, int meas_pi,
+                       void* K_out, int32_t* status, void* stream) {
+    if (!src) return DVI_ESKF_EINVAL;
+    return step_common(h, n_pred, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream, src);
 }
 
 int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) {

@@ -73,6 +73,10 @@ struct StepArgs {
     int rounds;         // instances per wave slot in the covariance kernel (set by the launcher)
     int apply_pending;  // the workspace holds the error state of the previous update: inject it first
     const void* noise;  // nullable [B][NOISE_WORDS]: per-instance diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
+    // where the step READS the covariance and the state record (another handle's buffers for
+    // dvi_eskf_step_from; otherwise the handle's own P / xs -- the step is then in place)
+    const void* P_src;
+    const void* xs_src;
 };
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     const int64_t b = live ? b_raw : a.B - 1;      // tail lanes recompute the last instance, write nothing
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
-    load_state(xs, a.B, b, s);
+    load_state(reinterpret_cast<const T*>(a.xs_src), a.B, b, s);
     // the pending error state is fetched together with its status word and the state (one round
     // trip to HBM, not two), whether or not the status lets it be applied
     T epend[24];
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         for (int i = 0; i < 7; ++i) gr[i] = r[i];
         gr[7] = flag;                                         // asin argument was clamped, or non-finite residual
     }
-    if (a.n_pred > 0 || a.apply_pending) store_state(xs, a.B, bo, s);
+    if (a.n_pred > 0 || a.apply_pending || a.xs_src != a.xs) store_state(xs, a.B, bo, s);   // (unchanged in place otherwise)
 }
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
     T jv[NJ];
 #define ESKF_ISSUE_LOADS(INST)                                                                     \
     {                                                                                              \
-        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P) + (INST) * 300); \
+        const T2* gP2_ = reinterpret_cast<const T2*>(reinterpret_cast<const T*>(a.P_src) + (INST) * 300); \
         _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                           \
             const int e2 = lig + k * LPI;                                                          \
             if (e2 < 150) pv[k] = gP2_[e2];                                                        \
@@ -1706,12 +1706,12 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     // image and gathered from there.
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
-        const T* gP_ = reinterpret_cast<const T*>(a.P) + (int64_t)inst * 300;                      \
+        const T* gP_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)inst * 300;                  \
         if (sizeof(T) == 8) {                                                                      \
             /* wave-uniform base (scalar registers) + an unsigned 32-bit lane offset: one address  \
                instruction per load instead of a sign extension and a 64-bit add */                \
             const int i0_ = (int)blockIdx.x * G;                                                   \
-            const T* gPw_ = reinterpret_cast<const T*>(a.P) + (int64_t)i0_ * 300;                  \
+            const T* gPw_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300;              \
             const unsigned io_ = (unsigned)(inst - i0_) * (300u * 8u);                             \
             unsigned gat_[24];                                                                     \
             _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = (unsigned)kRowsTables.gatp8[row][j]; \

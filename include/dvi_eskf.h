@@ -129,6 +129,16 @@ int dvi_eskf_epoch(dvi_eskf* h, int n_pred, const void* dt, int dt_per_instance,
                    const void* acc, int imu_per_instance, const void* pos, const void* quat_xyzw,
                    const void* notch, int meas_per_instance, void* K_out, int32_t* status, void* stream);
 
+/* dvi_eskf_epoch whose predicts start from ANOTHER handle's state: h <- epoch(src), src untouched.  What
+ * `copy.deepcopy(kf)` / Simulator.reset_kf (Simulator.py:150,160-161) followed by a run does, without
+ * the copy: a Monte-Carlo restart or a tuning candidate reads the common snapshot directly (P and the
+ * state record are read from src's buffers and written to h's).  Same batch size, dtype and device;
+ * h keeps its own noise model and parameters; a pending injection of src is applied to src first, one
+ * of h is dropped with the state it belonged to.  n_pred >= 0; the update always runs. */
+int dvi_eskf_step_from(dvi_eskf* h, dvi_eskf* src, int n_pred, const void* dt, int dt_per_instance, const void* om,
+                       const void* acc, int imu_per_instance, const void* pos, const void* quat_xyzw,
+                       const void* notch, int meas_per_instance, void* K_out, int32_t* status, void* stream);
+
 /* Filter.run (Filter.py:144-168): a whole run -- every camera frame's epoch -- enqueued by one
  * call, so that a long run costs one trip through the host binding instead of one per frame.
  * Epoch e consumes n_pred[e] consecutive IMU samples and measurement e; same kernels, same

@@ -189,3 +189,39 @@ def test_gather_calibration_through_rccl():
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("lpi", [None, 2, 32])
+def test_step_from_a_snapshot_equals_copy_then_step(lpi):
+    """dvi_eskf_step_from: h <- step(src) reads src's covariance and state record directly; bit for bit the
+    result of copying src into h and stepping in place; src is untouched; pending injections on either
+    side are handled (src's is applied to src first, h's is dropped with the state it belonged to)."""
+    f, ri, Q, R = _make(B=37, hold=False)
+    if lpi:
+        f.set_lanes_per_instance(lpi)
+    f.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])        # leaves an injection pending
+    snap = f.clone()                                                                 # (flushed copy)
+    snap.step(ri.dt[1], ri.om[1], ri.acc[1], ri.pos[1], ri.quat[1], ri.notch[1])     # snapshot WITH a pending injection
+    want_src = {k: v.clone() for k, v in snap.clone().get_state().items()}
+    a, b = f.clone(), f.clone()
+    if lpi:
+        a.set_lanes_per_instance(lpi); b.set_lanes_per_instance(lpi)
+    a.step(ri.dt[2], ri.om[2], ri.acc[2], ri.pos[2], ri.quat[2], ri.notch[2])        # a has its own pending injection
+    st_a, _ = a.step_from(snap, ri.dt[3], ri.om[3], ri.acc[3], ri.pos[3], ri.quat[3], ri.notch[3])
+    b.copy_state_from(snap)
+    st_b, _ = b.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[3], ri.quat[3], ri.notch[3])
+    assert torch.equal(st_a, st_b)
+    sa, sb, ss = a.get_state(), b.get_state(), snap.get_state()
+    for key in sa:
+        assert torch.equal(sa[key], sb[key]), key
+        assert torch.equal(ss[key], want_src[key]), key
+    # and it keeps going: a further in-place step agrees as well
+    a.step(ri.dt[4], ri.om[4], ri.acc[4], ri.pos[4], ri.quat[4], ri.notch[4])
+    b.step(ri.dt[4], ri.om[4], ri.acc[4], ri.pos[4], ri.quat[4], ri.notch[4])
+    assert torch.equal(a.x, b.x) and torch.equal(a.get_state()["P"], b.get_state()["P"])
+    # mismatched handles are refused
+    from dvi_ekf_amd import _capi
+    other, *_ = _make(B=5, hold=False)
+    L = _capi.lib()
+    assert L.dvi_eskf_step_from(a._h, other._h, 1, None, 0, None, None, 0, None, None, None, 0, None, None, None) == -1
+    assert L.dvi_eskf_step_from(a._h, None, 1, None, 0, None, None, 0, None, None, None, 0, None, None, None) == -1
