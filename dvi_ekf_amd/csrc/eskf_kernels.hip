@@ -1575,8 +1575,6 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
 struct RowsTables {                  // [v]: lane layout v = 0: 32 lanes per instance, v = 1: 24 lanes per instance
     int pos[2][32][16];
     int gat[24][24];
-    int gatp[24][24];    // packed-record word of P[row][j] (= of P[max][min])
-    int gatp8[24][24];   // ... as a byte offset (fp64)
     int jsrc[2][32][4];  // Jacobian record: the record words lane lig moves (clamped to the record) ...
     int jdst[2][32][4];  // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
 };
@@ -1602,12 +1600,7 @@ constexpr RowsTables make_rows_tables() {
         }
     }
     for (int r = 0; r < 24; ++r)
-        for (int j = 0; j < 24; ++j) {
-            t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
-            const int hi = j <= r ? r : j, lo = j <= r ? j : r;
-            t.gatp[r][j] = hi < 12 ? (25 * hi + lo) : (25 * (23 - hi) + (23 - hi) + 1 + lo);
-            t.gatp8[r][j] = 8 * (hi < 12 ? (25 * hi + lo) : (25 * (23 - hi) + (23 - hi) + 1 + lo));
-        }
+        for (int j = 0; j < 24; ++j) t.gat[r][j] = (j <= r) ? (r * 25 + j) : (j * 25 + r);
     return t;
 }
 __device__ const RowsTables kRowsTables = make_rows_tables();
@@ -1674,7 +1667,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
         asm volatile("" : "+v"(lj_));   /* (per-lane addresses formed here, not kept across rounds) */ \
         const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
         _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w_ = kRowsTables.jsrc[TV][lj_][k];                                           \
+            const int w_ = LPI == 32 ? lj_ + 32 * k : kRowsTables.jsrc[TV][lj_][k];   /* (same numbers) */ \
             DST[k] = gJ_[w_ < jlast ? w_ : jlast];   /* (the padding of the record is not fetched) */ \
         }                                                                                          \
         RES.x = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                \
@@ -1704,6 +1697,26 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     // version of that is texture-addresser bound (measured 18 % slower on the 1M-instance predict-only
     // configuration), so the record is fetched in 16-byte pieces, scattered into the lower-triangle LDS
     // image and gathered from there.
+#define ESKF_ISSUE_ROW()                                                                           \
+    {                                                                                              \
+            /* wave-uniform base (scalar registers) + an unsigned 32-bit lane offset: one address  \
+               instruction per load instead of a sign extension and a 64-bit add */                \
+            const int i0_ = (int)blockIdx.x * G;                                                   \
+            const T* gPw_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300;              \
+            const unsigned io_ = (unsigned)(inst - i0_) * (300u * 8u);                             \
+            /* byte offset of P[row][j] = P[max][min]: packed row hi starts at word 25 hi (hi < 12) or    \
+               26 (23 - hi) + 1, and holds its elements lo = 0..hi in order.  Formed with a compare and   \
+               a select per element instead of being read from a table in memory: the loads of the rows   \
+               then do not wait for a first round trip that only fetches their addresses */               \
+            const unsigned rw_ = (unsigned)row;                                                    \
+            const unsigned va_ = io_ + 8u * (rw_ < 12u ? 25u * rw_ : 26u * (23u - rw_) + 1u);      \
+            const unsigned vb_ = io_ + 8u * rw_;                                                   \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) {                                       \
+                const unsigned cj_ = 8u * (unsigned)(j < 12 ? 25 * j : 26 * (23 - j) + 1);         \
+                const unsigned o_ = ((unsigned)j <= rw_) ? va_ + 8u * (unsigned)j : vb_ + cj_;     \
+                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
+            }                                                                                      \
+    }
 #define ESKF_UNPACK_ROW()                                                                          \
     {                                                                                              \
         const T* gP_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)inst * 300;                  \
@@ -1713,10 +1726,18 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
             const int i0_ = (int)blockIdx.x * G;                                                   \
             const T* gPw_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300;              \
             const unsigned io_ = (unsigned)(inst - i0_) * (300u * 8u);                             \
-            unsigned gat_[24];                                                                     \
-            _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = (unsigned)kRowsTables.gatp8[row][j]; \
-            _Pragma("unroll") for (int j = 0; j < 24; ++j)                                         \
-                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)(io_ + gat_[j])); \
+            /* byte offset of P[row][j] = P[max][min]: packed row hi starts at word 25 hi (hi < 12) or    \
+               26 (23 - hi) + 1, and holds its elements lo = 0..hi in order.  Formed with a compare and   \
+               a select per element instead of being read from a table in memory: the loads of the rows   \
+               then do not wait for a first round trip that only fetches their addresses */               \
+            const unsigned rw_ = (unsigned)row;                                                    \
+            const unsigned va_ = io_ + 8u * (rw_ < 12u ? 25u * rw_ : 26u * (23u - rw_) + 1u);      \
+            const unsigned vb_ = io_ + 8u * rw_;                                                   \
+            _Pragma("unroll") for (int j = 0; j < 24; ++j) {                                       \
+                const unsigned cj_ = 8u * (unsigned)(j < 12 ? 25 * j : 26 * (23 - j) + 1);         \
+                const unsigned o_ = ((unsigned)j <= rw_) ? va_ + 8u * (unsigned)j : vb_ + cj_;     \
+                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
+            }                                                                                      \
             group_sync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
         } else {                                                                                   \
             const T2* gP2_ = reinterpret_cast<const T2*>(gP_);                                     \
@@ -1752,17 +1773,28 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     int inst = valid ? slot : nB - 1;
     int row = row0;
     asm volatile("" : "+v"(row), "+v"(inst));
-    {   // packed covariance into registers, first Jacobian record and residual into LDS
+    constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
+    T p[24];                                // row `row` of P
+    if constexpr (DPPJ && sizeof(T) == 8) {
+        // everything this wavefront reads is requested in one go -- the 24 row elements first, then the
+        // Jacobian record and the residual -- and waited for once: one memory round trip, not two
         T j0[NJ];
         T2 r0;
         r0.x = r0.y = T(0);
+        ESKF_ISSUE_ROW()
         ESKF_LOAD_J(j0, r0, inst, 0)
         ESKF_STAGE_J(j0, r0)
+        group_sync();       // (the staged residual is visible to every lane)
+    } else {
+        {   // first Jacobian record and residual into LDS, packed covariance into registers
+            T j0[NJ];
+            T2 r0;
+            r0.x = r0.y = T(0);
+            ESKF_LOAD_J(j0, r0, inst, 0)
+            ESKF_STAGE_J(j0, r0)
+        }
+        ESKF_UNPACK_ROW()
     }
-
-    constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
-    T p[24];                                // row `row` of P
-    ESKF_UNPACK_ROW()
 
     // ================================ predict(s) =======================================
     for (int ip = 0; ip < a.n_pred; ++ip) {
@@ -1971,6 +2003,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 #undef ESKF_LOAD_J
 #undef ESKF_STAGE_J
 #undef ESKF_UNPACK_ROW
+#undef ESKF_ISSUE_ROW
 #undef ESKF_PREDICT_ROWS
 }
 
