@@ -1813,6 +1813,14 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     // The 7 measurements one after the other; sv is the pivot d_m of S = L D L^T.  A zero or
     // non-finite pivot is the reference's LinAlgError (Filter.py:356-361: nothing changes): the
     // remaining measurements are skipped and the ones already applied are taken back.
+    // image positions of the packed-record words this lane will store, fetched now (table in memory): asked
+    // for at the point of use they cost every wavefront an exposed round trip right before its stores
+    int off[2 * NV];
+#pragma unroll
+    for (int k = 0; k < 2 * NV; ++k) off[k] = kRowsTables.pos[TV][lig][k];
+#pragma unroll
+    for (int k = 0; k < 2 * NV; ++k) asm volatile("" : "+v"(off[k]));
+
     T e = T(0);                             // component `row` of the error state
     int status = 0;
     bool fail = false;
@@ -1986,9 +1994,6 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     group_sync();
     if (valid) {
         T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
-        int off[2 * NV];
-#pragma unroll
-        for (int k = 0; k < 2 * NV; ++k) off[k] = kRowsTables.pos[TV][lig][k];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e2 = lig + k * LPI;
