@@ -1797,16 +1797,35 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     }
 
     // ================================ predict(s) =======================================
-    for (int ip = 0; ip < a.n_pred; ++ip) {
-        if (ip > 0) {                       // (the first record was staged at the end of the previous round)
+    if constexpr (DPPJ) {
+        // epochs: the record of the next predict is requested before this one is computed (six registers)
+        // and put in place after it; the last (or only) predict of a launch has nothing to fetch
+        for (int ip = 0; ip < a.n_pred; ++ip) {
+            const bool more = ip + 1 < a.n_pred;    // uniform
             T jn[NJ];
             T2 rn;
             rn.x = rn.y = T(0);
-            ESKF_LOAD_J(jn, rn, inst, ip)
-            ESKF_STAGE_J(jn, rn)
-            group_sync();
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) jn[k] = T(0);
+            if (more) ESKF_LOAD_J(jn, rn, inst, ip + 1)
+            ESKF_PREDICT_ROWS()
+            if (more) {
+                ESKF_STAGE_J(jn, rn)
+                group_sync();
+            }
         }
-        ESKF_PREDICT_ROWS()
+    } else {
+        for (int ip = 0; ip < a.n_pred; ++ip) {
+            if (ip > 0) {                   // (the first record was staged before the loop)
+                T jn[NJ];
+                T2 rn;
+                rn.x = rn.y = T(0);
+                ESKF_LOAD_J(jn, rn, inst, ip)
+                ESKF_STAGE_J(jn, rn)
+                group_sync();
+            }
+            ESKF_PREDICT_ROWS()
+        }
     }
 
     // ================================ update ===========================================
