@@ -130,6 +130,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step from Python instead of replaying a HIP graph")
     ap.add_argument("--per-instance-noise", action="store_true",
                     help="diagnostic: every instance carries its own (identical) noise record -- the tuning-population path")
+    ap.add_argument("--sustain-seconds", type=float, default=0.3,
+                    help="untimed load (replays of the captured horizon) between the warm-up steps and the timed region, so "
+                         "that a short timed region is measured at the GPU's sustained clocks; 0 = none")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the secondary measurement at --streaming-batch")
+    ap.add_argument("--streaming-batch", type=int, default=262144)
+    ap.add_argument("--dump-dofs", default=None, help="rank 0 saves the gathered calibration estimates [B_total,6] (.npy)")
     ap.add_argument("--mode", default="pair", choices=["pair", "predict", "update"],
                     help="diagnostic: time only the predict or only the update launch (not the metric)")
     args = ap.parse_args()
@@ -172,35 +178,108 @@ def main():
         if B % world:
             raise SystemExit("--strong: the total batch must divide evenly over the ranks")
         B //= world
-    wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, first_instance=rank * B)
-    f = wl.make_filter()
-    if args.lanes:
-        f.set_lanes_per_instance(args.lanes)
-    if args.per_instance_noise:
-        f.set_noise_per_instance(np.tile(np.diag(wl.Q), (B, 1)), np.tile(np.diag(wl.R), (B, 1)))
-    snap = f.clone()
-    status = torch.zeros(B, dtype=torch.int32, device=dev)
 
-    def pair(i):
-        """pair-step i of the horizon; the first one starts from the snapshot"""
-        if i == 0 and not args.restore_copy:
-            f.step_from(snap, wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
-            return
-        if i == 0:
-            f.copy_state_from(snap)
-        f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
-
-    def step(k):
-        pair(k % H)
+    backend = os.environ.get("DVI_BENCH_BACKEND", "nccl")   # "gloo" only for rehearsing the N>1 path on one GPU
 
     def barrier():
         if dist is not None:
-            if os.environ.get("DVI_BENCH_BACKEND", "nccl") == "nccl":
+            if backend == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
                 dist.barrier()
 
-    backend = os.environ.get("DVI_BENCH_BACKEND", "nccl")   # "gloo" only for rehearsing the N>1 path on one GPU
+    class Run:
+        """One filter batch + its snapshot + the captured horizon(s)."""
+
+        def __init__(self, batch, first_instance):
+            self.B = batch
+            self.wl = monte_carlo_pairs(batch, horizon=H, seed=4, device=dev, first_instance=first_instance)
+            self.f = self.wl.make_filter()
+            if args.lanes:
+                self.f.set_lanes_per_instance(args.lanes)
+            if args.per_instance_noise:
+                self.f.set_noise_per_instance(np.tile(np.diag(self.wl.Q), (batch, 1)), np.tile(np.diag(self.wl.R), (batch, 1)))
+            self.snap = self.f.clone()
+            self.status = torch.zeros(batch, dtype=torch.int32, device=dev)
+            self.graphs = {}
+
+        def pair(self, i):
+            """pair-step i of the horizon; the first one starts from the snapshot"""
+            wl, f = self.wl, self.f
+            if i == 0 and not args.restore_copy:
+                f.step_from(self.snap, wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=self.status)
+                return
+            if i == 0:
+                f.copy_state_from(self.snap)
+            f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=self.status)
+
+        def eager(self, k0, n):
+            for k in range(k0, k0 + n):
+                i = k % H
+                if args.mode == "pair":
+                    self.pair(i)
+                else:
+                    if i == 0:
+                        self.f.copy_state_from(self.snap)
+                    if args.mode == "predict":
+                        self.f.predict(self.wl.dt[i], self.wl.om[i], self.wl.acc[i])
+                    else:
+                        self.f.update(self.wl.pos[i], self.wl.quat[i], self.wl.notch[i])
+
+        def capture(self, n):
+            """steps 0..n-1 of a horizon as one HIP graph (n <= H): at ~0.1 ms of kernel time per step the
+            Python/ctypes launch path would otherwise show up in the step time"""
+            if n not in self.graphs:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self.eager(0, n)                         # warm-up on the capture stream
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self.eager(0, n)
+                torch.cuda.synchronize(dev)
+                self.graphs[n] = g
+            return self.graphs[n]
+
+        def plan(self, nsteps):
+            """the launches of `nsteps` consecutive steps: whole horizons, then the rest of one, each a graph
+            replay -- every step of the timed region is replayed, none is launched from Python"""
+            use_graph = args.mode == "pair" and not args.no_graph
+            full, rest = divmod(nsteps, H)
+            if not use_graph:
+                return [("eager", 0, nsteps)]
+            ops = [("graph", self.capture(H), H)] * full
+            if rest:
+                ops.append(("graph", self.capture(rest), rest))
+            return ops
+
+        def execute(self, ops):
+            k = 0
+            for kind, g, n in ops:
+                if kind == "graph":
+                    g.replay()
+                else:
+                    self.eager(k, n)
+                k += n
+
+        def sustain(self, seconds):
+            """untimed: keeps the GPU under this very load until its clocks have settled (a cold GPU reads
+            ~15 % low over the first tens of milliseconds: 4.5e8 over 9 ms against 5.2e8 over 0.13 s, same build)"""
+            if seconds <= 0 or args.mode != "pair" or args.no_graph:
+                return 0
+            g, n = self.capture(H), 0
+            t_end = time.perf_counter() + seconds
+            while time.perf_counter() < t_end:
+                for _ in range(8):
+                    g.replay()
+                torch.cuda.synchronize(dev)
+                n += 8 * H
+            return n
+
+    run = Run(B, rank * B)
+    wl, f, status = run.wl, run.f, run.status
 
     def all_gather_dofs(dofs):
         if backend == "nccl":
@@ -211,82 +290,41 @@ def main():
             for g_, h_ in zip(gathered, host):
                 g_.copy_(h_)
 
-    for k in range(W):
-        step(k)
+    run.eager(0, W)                                          # the W warm-up steps
     gathered = None
     if dist is not None:   # warm the collective up as well
         gathered = [torch.empty((B, 6), dtype=torch.float64, device=dev) for _ in range(world)]
         all_gather_dofs(f.calibration())
     torch.cuda.synchronize(dev)
-
-    # One horizon (state restore + H pair-steps) is captured into a HIP graph: at ~0.19 ms of
-    # kernel time per step the Python/ctypes launch path would otherwise show up in the step time.
-    graph = None
-    if args.mode == "pair" and not args.no_graph and K >= H:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for k in range(H):
-                step(k)                                      # warm-up on the capture stream
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            for k in range(H):
-                step(k)
-        torch.cuda.synchronize(dev)
+    ops = run.plan(K)                                        # (captures the graphs: outside the timed region)
+    sustained_steps = run.sustain(args.sustain_seconds)
 
     barrier()
     torch.cuda.synchronize(dev)
+    ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
-    k = 0
-    ev_graph = None
-    if graph is not None:
-        # HIP events on the launch stream around the replayed steps of the timed region: GPU-side duration
-        # of the steps themselves, free of the host's launch pace
-        ev_graph = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        ev_graph[0].record()
-        while k + H <= K:
-            graph.replay()
-            k += H
-        ev_graph[1].record()
-        k_graph = k
-    while k < K:                                             # remainder (or everything, without a graph)
-        i = k % H
-        if args.mode == "pair":
-            pair(i)
-        else:
-            if i == 0:
-                f.copy_state_from(snap)
-            if args.mode == "predict":
-                f.predict(wl.dt[i], wl.om[i], wl.acc[i])
-            else:
-                f.update(wl.pos[i], wl.quat[i], wl.notch[i])
-        k += 1
+    ev_t[0].record()                                         # HIP events on the launch stream around the K steps
+    run.execute(ops)
+    ev_t[1].record()
     dofs = f.calibration()
     if dist is not None:
         all_gather_dofs(dofs)
     torch.cuda.synchronize(dev)
     barrier()
     elapsed = time.perf_counter() - t0
+    graph = any(o[0] == "graph" for o in ops)
+    kern_ms = ev_t[0].elapsed_time(ev_t[1]) / K
 
-    # kernel time of one step: HIP events around each launch group, eager, outside the timed region
+    if args.dump_dofs and rank == 0:
+        allv = torch.cat(gathered, dim=0) if gathered is not None else dofs
+        np.save(args.dump_dofs, allv.cpu().numpy())
+
+    # kernel time of one step from eagerly launched steps (diagnostic; contains the host's launch gaps)
     n_ev = min(K, 2 * H)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for k in range(n_ev):
-        i = k % H
-        if i == 0 and (args.mode != "pair" or args.restore_copy):
-            f.copy_state_from(snap)
         ev[k][0].record()
-        if args.mode == "pair":
-            if i == 0 and not args.restore_copy:
-                f.step_from(snap, wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
-            else:
-                f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=status)
-        elif args.mode == "predict":
-            f.predict(wl.dt[i], wl.om[i], wl.acc[i])
-        else:
-            f.update(wl.pos[i], wl.quat[i], wl.notch[i])
+        run.eager(k, 1)
         ev[k][1].record()
     torch.cuda.synchronize(dev)
 
@@ -295,9 +333,31 @@ def main():
     x_fin = f.x
     ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
     kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    # per-step duration for the roofline: over the timed region when it was replayed as a graph (the eager
-    # figure then also contains whatever the host needed between the two launches of a step)
-    kern_ms = ev_graph[0].elapsed_time(ev_graph[1]) / k_graph if (ev_graph is not None and k_graph > 0) else kern_ms_eager
+
+    # the same measurement at a batch whose working set does not fit the 256 MiB Infinity Cache (the headline
+    # batch's ~225 MB does): what the step sustains when it has to stream from HBM
+    streaming = None
+    if rank == 0 and world == 1 and args.mode == "pair" and not args.no_streaming and not args.no_graph:
+        Bs = args.streaming_batch
+        del run.graphs
+        big = Run(Bs, 0)
+        nS = 4 * H
+        big.eager(0, H)
+        ops_s = big.plan(nS)
+        big.sustain(min(args.sustain_seconds, 0.2))
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        big.execute(ops_s)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / nS
+        ok_s = bool((big.status.cpu().numpy() == 0).all())
+        ach = BYTES_PER_PAIR_F64 * Bs / (ms * 1e-3) / 1e9
+        streaming = {"batch": Bs, "steps": nS, "kernel_ms": ms, "pair_steps_per_s": Bs / (ms * 1e-3), "achieved": ach,
+                     "frac": ach / HBM_PEAK_GBS, "valid": ok_s,
+                     "note": "working set ~%d MB: streams from HBM (Infinity Cache 256 MiB)" % (Bs * 3450 // 1000000)}
+        del big
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist is not None:
@@ -308,11 +368,14 @@ def main():
         total_pairs = float(B) * world * K
         value = total_pairs / elapsed
         achieved = BYTES_PER_PAIR_F64 * B / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        achieved_wall = BYTES_PER_PAIR_F64 * B / (elapsed / K) / 1e9
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.exists(tf):
             try:
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                traffic_source = ("static: profiles/traffic_per_launch.json -- a constant taken from the committed rocprofv3 "
+                                  "PMC pass of this kernel pair (FETCH_SIZE x2 + WRITE_SIZE per step), NOT measured in this run")
             except Exception:
                 traffic = None
         out = {
@@ -337,15 +400,24 @@ def main():
                 "state_restore": "device-to-device copy of the snapshot" if args.restore_copy else
                                  "the first pair-step of a horizon reads the snapshot handle (dvi_eskf_step_from)",
                 "covariance_kernel": "row-resident" if (args.lanes or 1) == 1 else "lds-image, %d lanes/instance" % args.lanes,
-                "hip_graph": graph is not None,
+                "hip_graph": graph,
+                "timed_region": "every one of the %d steps is a HIP-graph replay (whole horizons + one graph for the rest)" % K
+                                if graph else "steps launched from Python",
+                "untimed_preparation": "%d warm-up steps, graph capture, then %d replayed steps (%.2f s) to reach sustained clocks"
+                                       % (W, sustained_steps, args.sustain_seconds),
                 "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "one step = eskf_pre_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes); HIP events on the launch stream around the replayed steps of the timed region",
+                "frac": achieved / HBM_PEAK_GBS,
+                "frac_wall": achieved_wall / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "one step = eskf_pre_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes)",
+                "timing": "frac: HIP events on the launch stream around the K steps of the timed region; frac_wall: from "
+                          "ms_per_step (host clock, includes the final calibration read, the synchronisation and barriers)",
                 "kernel_ms": kern_ms, "kernel_ms_eager_launches": kern_ms_eager,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR_F64 * B,
+                "streaming": streaming,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

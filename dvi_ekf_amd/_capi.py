@@ -60,10 +60,14 @@ SIGNATURES = {
     "dvi_eskf_get_calibration": (_i, [_vp, _vp, _vp]),
     "dvi_eskf_gather_calibration": (_i, [_vp, _vp, _vp, _vp]),
     "dvi_eskf_flush": (_i, [_vp, _vp]),
+    "dvi_eskf_reserve": (_i, [_vp, _i]),
+    "dvi_eskf_keep_jacobians": (_i, [_vp, _i]),
+    "dvi_eskf_get_jacobians": (_i, [_vp, _vp, _vp, _vp]),
     "dvi_eskf_raw_P": (_vp, [_vp]),
     "dvi_eskf_raw_x": (_vp, [_vp]),
     "dvi_eskf_set_lanes_per_instance": (_i, [_vp, _i]),
     "dvi_eskf_log_rows": (_i, [_vp, C.c_double, _vp, _vp]),
+    "dvi_eskf_update_mse": (_i, [_vp, _dp, _dp, _vp, _vp]),
     "dvi_eskf_imu_synthesize": (_i, [C.POINTER(Params), _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _dp, _vp, _vp,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
     "dvi_eskf_randn": (_i, [_i, _i, C.c_uint64, _i64, _i64, _i64, _i64, _i, _vp, _vp]),

@@ -111,6 +111,35 @@ class BatchedESKF:
         _capi.check(self.lib.dvi_eskf_log_rows(self._h, float(t), _ptr(rows), self._stream()), "dvi_eskf_log_rows")
         return rows
 
+    def reserve(self, n_pred: int) -> None:
+        """Size the workspace for epochs of up to ``n_pred`` predicts (needed before capturing such an
+        epoch into a HIP graph; optional otherwise)."""
+        _capi.check(self.lib.dvi_eskf_reserve(self._h, int(n_pred)), "dvi_eskf_reserve")
+
+    def flush(self) -> None:
+        _capi.check(self.lib.dvi_eskf_flush(self._h, self._stream()), "dvi_eskf_flush")
+
+    def keep_jacobians(self, on: bool = True) -> None:
+        """Let every predict leave what ``jacobians()`` needs (Filter.Fx / Filter.Fi) in the workspace."""
+        _capi.check(self.lib.dvi_eskf_keep_jacobians(self._h, int(bool(on))), "dvi_eskf_keep_jacobians")
+
+    def jacobians(self):
+        """(Fx [B,24,24], Fi [B,24,13]) of the last predict (Filter.py:249-268,279-285)."""
+        Fx = torch.empty((self.batch, 24, 24), dtype=self.dtype, device=self.device)
+        Fi = torch.empty((self.batch, 24, 13), dtype=self.dtype, device=self.device)
+        _capi.check(self.lib.dvi_eskf_get_jacobians(self._h, _ptr(Fx), _ptr(Fi), self._stream()), "dvi_eskf_get_jacobians")
+        return Fx, Fi
+
+    def update_mse(self, cam_ref6, imu_ref6=None) -> torch.Tensor:
+        """Filter.calculate_update_mse (Filter.py:397-418) of every instance [B], reduced on the device."""
+        dp = C.POINTER(C.c_double)
+        cam = np.ascontiguousarray(np.asarray(cam_ref6, dtype=np.float64).reshape(6))
+        imu = None if imu_ref6 is None else np.ascontiguousarray(np.asarray(imu_ref6, dtype=np.float64).reshape(6))
+        out = torch.empty(self.batch, dtype=self.dtype, device=self.device)
+        _capi.check(self.lib.dvi_eskf_update_mse(self._h, cam.ctypes.data_as(dp), None if imu is None else imu.ctypes.data_as(dp),
+                                                 _ptr(out), self._stream()), "dvi_eskf_update_mse")
+        return out
+
     def set_lanes_per_instance(self, lanes: int) -> None:
         _capi.check(self.lib.dvi_eskf_set_lanes_per_instance(self._h, int(lanes)), "set_lanes_per_instance")
 

@@ -216,7 +216,13 @@ class Camera:
         included, then re-normalisation (Interpolator.py:25-88)."""
         t_old = self.t
         n_new = (len(t_old) - 1) * interframe_vals + 1
-        t_new = np.linspace(t_old[0], t_old[-1], num=n_new)
+        return self.interpolate_to(np.linspace(t_old[0], t_old[-1], num=n_new), interframe_vals)
+
+    def interpolate_to(self, t_new, interframe_vals: int = 0) -> "Camera":
+        """The interpolation of ``interpolate`` on an arbitrary time grid (an IMU clock that is not a
+        multiple of the frame rate: 1 kHz against 30 Hz, BASELINE config #5)."""
+        t_old = self.t
+        t_new = np.asarray(t_new, dtype=float)
         table = {"t": t_new}
         for c in _COLS[1:]:
             table[c] = np.interp(t_new, t_old, getattr(self.traj, c))

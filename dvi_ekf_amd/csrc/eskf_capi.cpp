@@ -26,8 +26,14 @@ struct dvi_eskf {
     void* d_res;        // [B][8]
     void* d_e;          // [B][24]
     int32_t* d_status;  // [B]
-    bool pending;       // d_e / d_status hold an update whose injection into d_x is still due
+    // Deferred injection: WHETHER an instance's error state still awaits injection is device state (bit
+    // DVI_STATUS_PENDING of d_status, set by the covariance kernel, cleared by the kernel that injects).
+    // The host only keeps a hint so that it can skip work it knows to be pointless:
+    bool maybe_pending; // an update has been enqueued since the last flush
+    bool captured;      // a step of this handle was recorded into a HIP graph: replays change the device
+                        // state behind the host's back, so from then on the hint is always "maybe"
     void* d_noise;      // nullable [B][NOISE_WORDS]: per-instance diag(Q) | diag(R) | sigma_om
+    int jac_ip;         // record of the last predict in d_J when it was written in full (keep_jac), else -1
 };
 
 namespace {
@@ -66,17 +72,27 @@ bool alloc_buffers(dvi_eskf* h) {
     return true;
 }
 
-// grow the Jacobian workspace for an n_pred-step epoch (allocation: not graph-capturable;
-// happens once per handle and epoch length)
-bool ensure_jcap(dvi_eskf* h, int n_pred) {
-    if (n_pred <= h->jcap) return true;
+bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
+    return st != hipStreamCaptureStatusNone;
+}
+
+// Grow the Jacobian workspace for an n_pred-step epoch.  An allocation and a device-wide
+// synchronisation: neither is allowed while a stream is being captured, so a capturing caller must have
+// sized the workspace beforehand (dvi_eskf_reserve, or one eager epoch of that length) -- DVI_ESKF_ECAPTURE
+// otherwise.  Happens at most once per handle and epoch length.
+int ensure_jcap(dvi_eskf* h, int n_pred, hipStream_t stream) {
+    if (n_pred <= h->jcap) return DVI_ESKF_OK;
+    if (stream_is_capturing(stream)) return DVI_ESKF_ECAPTURE;
     void* nj = nullptr;
-    if (hipMalloc(&nj, (size_t)n_pred * (size_t)h->B * eskf::JAC_WORDS * elem_size(h->dtype)) != hipSuccess) return false;
+    if (hipMalloc(&nj, (size_t)n_pred * (size_t)h->B * eskf::JAC_WORDS * elem_size(h->dtype)) != hipSuccess) return DVI_ESKF_ENOMEM;
     (void)hipDeviceSynchronize();   // earlier launches may still read the old workspace
     (void)hipFree(h->d_J);
     h->d_J = nj;
     h->jcap = n_pred;
-    return true;
+    h->jac_ip = -1;
+    return DVI_ESKF_OK;
 }
 
 struct DeviceGuard {
@@ -103,12 +119,14 @@ eskf::StepArgs base_args(const dvi_eskf* h) {
     return a;
 }
 
-// apply a deferred injection so that d_x is the state the caller expects to see
+// apply a deferred injection so that d_x is the state the caller expects to see: the flush kernel
+// injects where the device says an injection is due and does nothing elsewhere
 int flush_pending(dvi_eskf* h, hipStream_t stream) {
-    if (!h->pending) return DVI_ESKF_OK;
+    if (stream_is_capturing(stream)) h->captured = true;
+    if (!h->maybe_pending && !h->captured) return DVI_ESKF_OK;
     eskf::StepArgs a = base_args(h);
     if (eskf::launch_flush(h->dtype, a, h->hp, stream) != hipSuccess) return DVI_ESKF_EHIP;
-    h->pending = false;
+    h->maybe_pending = false;
     return DVI_ESKF_OK;
 }
 
@@ -124,7 +142,8 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     if (n_pred == 0 && !do_update) return DVI_ESKF_OK;
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
-    if (!ensure_jcap(h, n_pred)) return DVI_ESKF_ENOMEM;
+    if (int rc = ensure_jcap(h, n_pred, (hipStream_t)stream)) return rc;
+    if (stream_is_capturing((hipStream_t)stream)) h->captured = true;
     eskf::StepArgs a = base_args(h);
     a.dt = dt; a.om = om; a.acc = acc;
     a.pos = pos; a.quat = quat; a.notch = notch;
@@ -135,16 +154,18 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     a.dt_stride = dt_pi ? 1 : 0;
     a.imu_stride = imu_pi ? 1 : 0;
     a.meas_stride = meas_pi ? 1 : 0;
-    a.apply_pending = h->pending ? 1 : 0;
+    a.pending_hint = (h->maybe_pending || h->captured) ? 1 : 0;
     if (src) {      // read the other handle's (flushed) state; whatever this handle held is replaced
         if (flush_pending(src, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
         a.P_src = src->d_P;
         a.xs_src = src->d_x;
-        a.apply_pending = 0;
+        a.drop_pending = 1;
     }
     hipError_t e = eskf::launch_step(h->dtype, h->lpi, a, h->hp, (hipStream_t)stream);
     if (e != hipSuccess) return DVI_ESKF_EHIP;
-    h->pending = do_update != 0;      // this update's injection is applied by the next step or a flush
+    // the pre kernel has consumed what was due; this step's update (if any) leaves its own error state behind
+    h->maybe_pending = do_update != 0;
+    if (n_pred > 0) h->jac_ip = h->hp.keep_jac ? n_pred - 1 : -1;
     return DVI_ESKF_OK;
 }
 
@@ -162,8 +183,9 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     if (!g.ok) return DVI_ESKF_ENODEV;
     dvi_eskf* h = new (std::nothrow) dvi_eskf();
     if (!h) return DVI_ESKF_ENOMEM;
-    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 1; h->pending = false; h->d_noise = nullptr;
-    h->hp.q_gyro_any = 0;
+    h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 1; h->d_noise = nullptr;
+    h->maybe_pending = false; h->captured = false; h->jac_ip = -1;
+    h->hp.q_gyro_any = 0; h->hp.keep_jac = 0;
     h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
     h->hp.frozen_mask = 0;
     for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);
@@ -176,8 +198,16 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
         delete h;
         return DVI_ESKF_ENOMEM;
     }
-    (void)hipMemset(h->d_P, 0, (size_t)batch * 300 * es);
-    (void)hipMemset(h->d_x, 0, (size_t)batch * 36 * es);
+    // zeroed records, complete before this call returns: the caller's first call may run on any stream
+    // (torch side streams do not synchronise with the null stream these memsets run on)
+    if (hipMemsetAsync(h->d_P, 0, (size_t)batch * 300 * es, nullptr) != hipSuccess ||
+        hipMemsetAsync(h->d_x, 0, (size_t)batch * 36 * es, nullptr) != hipSuccess ||
+        hipMemsetAsync(h->d_status, 0, (size_t)batch * sizeof(int32_t), nullptr) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess) {
+        free_buffers(h);
+        delete h;
+        return DVI_ESKF_EHIP;
+    }
     *out = h;
     return DVI_ESKF_OK;
 }
@@ -197,6 +227,9 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
         return DVI_ESKF_ENOMEM;
     }
     hipStream_t s = (hipStream_t)stream;
+    h->maybe_pending = false;         // the copy starts from the flushed state: nothing is due on it
+    h->captured = stream_is_capturing(s);
+    h->jac_ip = -1;
     const size_t noise_bytes = (size_t)src->B * eskf::NOISE_WORDS * es;
     if (src->d_noise && hipMalloc(&h->d_noise, noise_bytes) != hipSuccess) {
         h->d_noise = nullptr;
@@ -204,7 +237,8 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
         delete h;
         return DVI_ESKF_ENOMEM;
     }
-    if (hipMemcpyAsync(h->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+    if (hipMemsetAsync(h->d_status, 0, (size_t)src->B * sizeof(int32_t), s) != hipSuccess ||
+        hipMemcpyAsync(h->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(h->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
         (src->d_noise && hipMemcpyAsync(h->d_noise, src->d_noise, noise_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)) {
         free_buffers(h);
@@ -220,9 +254,13 @@ int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
     DeviceGuard g(src->device);
     if (!g.ok) return DVI_ESKF_EHIP;
     if (flush_pending(const_cast<dvi_eskf*>(src), (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
-    dst->pending = false;             // whatever was due on dst is overwritten
     const size_t es = elem_size(src->dtype);
     hipStream_t s = (hipStream_t)stream;
+    if (stream_is_capturing(s)) dst->captured = true;
+    // whatever was due on dst is overwritten together with the state it belonged to
+    if ((dst->maybe_pending || dst->captured) &&
+        hipMemsetAsync(dst->d_status, 0, (size_t)dst->B * sizeof(int32_t), s) != hipSuccess) return DVI_ESKF_EHIP;
+    dst->maybe_pending = false;
     if (hipMemcpyAsync(dst->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
         hipMemcpyAsync(dst->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return DVI_ESKF_EHIP;
@@ -374,7 +412,7 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
         for (int64_t e = 0; e < sc->n_epochs; ++e) longest = sc->n_pred[e] > longest ? sc->n_pred[e] : longest;
         DeviceGuard g(h->device);
         if (!g.ok) return DVI_ESKF_EHIP;
-        if (!ensure_jcap(h, longest)) return DVI_ESKF_ENOMEM;
+        if (int rc = ensure_jcap(h, longest, (hipStream_t)stream)) return rc;
     }
     const size_t es = elem_size(h->dtype);
     const size_t B = (size_t)h->B;
@@ -444,6 +482,29 @@ int dvi_eskf_gather_calibration(dvi_eskf* h, void* dofs_all, void* rccl_comm, vo
     return rc;
 }
 
+int dvi_eskf_reserve(dvi_eskf* h, int n_pred) {
+    if (!h || n_pred < 0) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    return ensure_jcap(h, n_pred, nullptr);
+}
+
+int dvi_eskf_keep_jacobians(dvi_eskf* h, int on) {
+    if (!h) return DVI_ESKF_EINVAL;
+    h->hp.keep_jac = on ? 1 : 0;
+    h->jac_ip = -1;
+    return DVI_ESKF_OK;
+}
+
+int dvi_eskf_get_jacobians(const dvi_eskf* h, void* Fx_out, void* Fi_out, void* stream) {
+    if (!h || !Fx_out || !Fi_out) return DVI_ESKF_EINVAL;
+    if (h->jac_ip < 0) return DVI_ESKF_EINVAL;     // no predict since dvi_eskf_keep_jacobians(h, 1)
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_jacobians(h->dtype, h->B, h->d_J, h->jac_ip, Fx_out, Fi_out, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
 int dvi_eskf_flush(dvi_eskf* h, void* stream) {
     if (!h) return DVI_ESKF_EINVAL;
     DeviceGuard g(h->device);
@@ -467,6 +528,15 @@ int dvi_eskf_log_rows(dvi_eskf* h, double t, void* rows_out, void* stream) {
     if (!g.ok) return DVI_ESKF_EHIP;
     if (flush_pending(h, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
     hipError_t e = eskf::launch_log_rows(h->dtype, h->B, h->d_x, t, rows_out, (hipStream_t)stream);
+    return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+}
+
+int dvi_eskf_update_mse(dvi_eskf* h, const double* cam_ref6, const double* imu_ref6, void* mse_out, void* stream) {
+    if (!h || !cam_ref6 || !mse_out) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    if (flush_pending(h, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+    hipError_t e = eskf::launch_update_mse(h->dtype, h->B, h->d_x, cam_ref6, imu_ref6, mse_out, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
 
@@ -514,6 +584,7 @@ const char* dvi_eskf_strerror(int code) {
         case DVI_ESKF_ENODEV: return "no usable HIP device";
         case DVI_ESKF_ENOMEM: return "device memory allocation failed";
         case DVI_ESKF_EHIP: return "HIP runtime call or kernel launch failed";
+        case DVI_ESKF_ECAPTURE: return "the stream is being captured and the call would have to allocate: reserve first";
         default: return "unknown error";
     }
 }

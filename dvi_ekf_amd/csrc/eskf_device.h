@@ -10,6 +10,7 @@ namespace eskf {
 
 constexpr int DVI_STATUS_SINGULAR = 1;
 constexpr int DVI_STATUS_NONFINITE = 2;
+constexpr int DVI_STATUS_PENDING = 1 << 30;   // workspace word only: the update's error state is not injected yet
 constexpr int JAC_WORDS = 88;
 constexpr int NOISE_WORDS = 24; // per-instance noise record: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad   // words per Jacobian record (eskf_kernels.hip: JW)
 
@@ -24,6 +25,8 @@ struct DevParams {
     int frozen_mask;    // bit i: DOF i frozen
     int hold_frozen;    // 0: zero frozen DOFs after predict (Filter.py:243-245); 1: hold
     int q_gyro;         // diag(Q)[3:6] has a non-zero entry
+    int jfull;          // the pre kernel writes 85-word Jacobian records (with the N6 block): q_gyro, or the
+                        // handle keeps the Jacobians for dvi_eskf_get_jacobians
 };
 
 struct HostParams {
@@ -32,6 +35,7 @@ struct HostParams {
     double qd[13], r[7];
     int frozen_mask, hold_frozen;
     int q_gyro_any;     // per-instance noise: some instance has a non-zero gyro block in Q
+    int keep_jac;       // dvi_eskf_keep_jacobians: full Jacobian records although Q has no gyro block
 };
 
 template <typename T>
@@ -46,6 +50,7 @@ inline DevParams<T> make_dev_params(const HostParams& h) {
     d.frozen_mask = h.frozen_mask;
     d.hold_frozen = h.hold_frozen;
     d.q_gyro = (h.qd[3] != 0.0 || h.qd[4] != 0.0 || h.qd[5] != 0.0 || h.q_gyro_any) ? 1 : 0;
+    d.jfull = (d.q_gyro || h.keep_jac) ? 1 : 0;
     return d;
 }
 
@@ -71,7 +76,9 @@ struct StepArgs {
     int do_update;
     int dt_stride, imu_stride, meas_stride;
     int rounds;         // instances per wave slot in the covariance kernel (set by the launcher)
-    int apply_pending;  // the workspace holds the error state of the previous update: inject it first
+    int pending_hint;   // 0: the host knows that no instance has DVI_STATUS_PENDING set (nothing to fetch);
+                        // 1: look at the status words
+    int drop_pending;   // step_from: a pending injection of this handle is dropped with the state it belonged to
     const void* noise;  // nullable [B][NOISE_WORDS]: per-instance diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
     // where the step READS the covariance and the state record (another handle's buffers for
     // dvi_eskf_step_from; otherwise the handle's own P / xs -- the step is then in place)
@@ -91,6 +98,13 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
                       void* p_BW, void* R_WB, void* v_BW, const double* dofs6, const HostParams& hp, hipStream_t stream);
 
 hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream);
+
+// Filter.calculate_update_mse per instance: cam6 / imu6 host references (imu6 nullable), mse [B] device
+hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double* cam6, const double* imu6, void* mse,
+                             hipStream_t stream);
+
+// Fx [B,24,24] and Fi [B,24,13] of the predict whose (full, 85-word) record is J[ip]
+hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, hipStream_t stream);
 
 // eskf_noise.hip -- kind: 0 = normals f64, 1 = normals f32, 2 = raw Philox words (uint32 x 4 per triple)
 hipError_t launch_randn(int kind, uint64_t seed, int64_t first_instance, int64_t n_instances, int64_t first_step,

@@ -362,7 +362,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
         J.Em[3] = -hs[2]; J.Em[4] = T(1);   J.Em[5] = hs[0];
         J.Em[6] = hs[1];  J.Em[7] = -hs[0]; J.Em[8] = T(1);
         // noise Jacobian camera rows (only needed when the gyro block of Q is non-zero)
-        if (prm.q_gyro) {   // (without it the record ends after dt: the caller's staging rows are 67 words)
+        if (prm.jfull) {    // (without it the record ends after dt: the caller's staging rows are 67 words)
             T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
             mat3_skew(Ro, dp, J.N6);
 #pragma unroll
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     // (both odd -> conflict-free); sized by the launcher: 34 KB lets four blocks share a CU
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sJ = reinterpret_cast<T*>(smem_raw);
-    const int JS = prm.q_gyro ? J_FULL : J_CORE;
+    const int JS = prm.jfull ? J_FULL : J_CORE;
     const int lane = threadIdx.x & 63;
     const bool jac_role = threadIdx.x >= 64;           // wave-uniform
     const int64_t b0 = (int64_t)blockIdx.x * 64;
@@ -471,16 +471,23 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(reinterpret_cast<const T*>(a.xs_src), a.B, b, s);
-    // the pending error state is fetched together with its status word and the state (one round
-    // trip to HBM, not two), whether or not the status lets it be applied
+    // Deferred injection.  Whether the workspace holds an update whose error state is still to be
+    // injected is DEVICE state -- bit DVI_STATUS_PENDING of the instance's status word, set by the
+    // covariance kernel, cleared here (or by the flush kernel) -- so that a captured sequence of steps
+    // replays correctly whatever the host knew when it was captured.  The launcher only passes a hint:
+    // a.pending_hint == 0 promises that no instance has the bit set (predict-only sequences then do not
+    // fetch 24 words per instance for nothing).  The error state is fetched together with the status
+    // word and the state -- one round trip to HBM, not two -- whether or not the status lets it be applied.
     T epend[24];
     int pend_status = 0;
-    if (a.apply_pending) {
+    if (a.pending_hint) {
         pend_status = a.status_ws[b];
 #pragma unroll
         for (int i = 0; i < 24; ++i) epend[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i];
     }
-    const bool inject_now = a.apply_pending && !(pend_status & DVI_STATUS_SINGULAR);
+    // (dvi_eskf_step_from reads another handle's flushed state: whatever was due on this one is dropped)
+    const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
+    const bool inject_now = was_pending && !a.drop_pending && !(pend_status & DVI_STATUS_SINGULAR);
     // ... and so is the first IMU sample (the following ones are fetched at the end of the predict before)
     T dt0, om0[3], acc0[3];
     load_imu_sample(a, 0, b, dt0, om0, acc0);
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     if (inject_now) inject_error(s, epend);        // the previous update's injection (both roles)
     if (jac_role) {
         // ---- wave 1: Jacobian blocks of every predict of this launch ---------------------------
-        const int npiece = prm.q_gyro ? 43 : 34;   // 16-byte pieces of a record: 85 / 67 words
+        const int npiece = prm.jfull ? 43 : 34;    // 16-byte pieces of a record: 85 / 67 words
         // Jacobian evaluation point n = sigma (Filter.py:330-333): per instance when the handle carries
         // per-instance noise
         T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
@@ -581,7 +588,8 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         for (int i = 0; i < 7; ++i) gr[i] = r[i];
         gr[7] = flag;                                         // asin argument was clamped, or non-finite residual
     }
-    if (a.n_pred > 0 || a.apply_pending || a.xs_src != a.xs) store_state(xs, a.B, bo, s);   // (unchanged in place otherwise)
+    if (a.n_pred > 0 || a.pending_hint || a.xs_src != a.xs) store_state(xs, a.B, bo, s);   // (unchanged in place otherwise)
+    if (was_pending) a.status_ws[bo] = pend_status & ~DVI_STATUS_PENDING;                  // the injection is done (or dropped)
 }
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
@@ -610,7 +618,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T> prm) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
-    if (a.status_ws[b] & DVI_STATUS_SINGULAR) return;         // Filter.py:356-361: nothing changes
+    const int st = a.status_ws[b];
+    if (!(st & DVI_STATUS_PENDING)) return;                    // nothing due for this instance
+    a.status_ws[b] = st & ~DVI_STATUS_PENDING;
+    if (st & DVI_STATUS_SINGULAR) return;                      // Filter.py:356-361: nothing changes
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
@@ -1012,7 +1023,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
         }
         group_sync();
         if (lig == 0 && valid) {
-            a.status_ws[inst] = status;
+            a.status_ws[inst] = status | DVI_STATUS_PENDING;   // the error state of this update awaits injection
             if (a.status) a.status[inst] = status;
         }
     }
@@ -2000,7 +2011,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
         }
         group_sync();
         if (lig == 0 && valid) {
-            a.status_ws[inst] = status;
+            a.status_ws[inst] = status | DVI_STATUS_PENDING;   // the error state of this update awaits injection
             if (a.status) a.status[inst] = status;
         }
     }
@@ -2219,6 +2230,89 @@ __global__ __launch_bounds__(256) void eskf_log_rows_kernel(int64_t B, const T* 
     r[26] = s.qc[3]; r[27] = s.qc[0]; r[28] = s.qc[1]; r[29] = s.qc[2];
 }
 
+// Filter.calculate_update_mse (Filter.py:397-418) as a reduction over the log row of every instance: the
+// mean of the 12 squared differences between the camera columns xc yc zc rx_degc ry_degc rz_degc of the row
+// and the camera frame's x y z rx_deg ry_deg rz_deg, and between the IMU columns vx vy vz rx ry rz of the row
+// and the last IMU reference sample.  ref[0:6] = camera reference, ref[6:12] = IMU reference (shared by the
+// batch; has_imu = 0: the IMU half is left out of the sum, as when no reference trajectory is kept).
+struct MseRef { double v[12]; int has_imu; };
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_update_mse_kernel(int64_t B, const T* xs, MseRef ref, T* mse) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    State<T> s;
+    load_state(xs, B, b, s);
+    T e[3], ec[3];
+    euler_xyz_deg(s.q, e);
+    euler_xyz_deg(s.qc, ec);
+    T sum = T(0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T d0 = T(ref.v[i]) - s.pc[i], d1 = T(ref.v[3 + i]) - ec[i];
+        sum += d0 * d0 + d1 * d1;
+    }
+    if (ref.has_imu) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T d0 = s.v[i] - T(ref.v[6 + i]), d1 = e[i] - T(ref.v[9 + i]);
+            sum += d0 * d0 + d1 * d1;
+        }
+    }
+    mse[b] = sum / T(12);
+}
+
+// ----------------------------------------------------------------------------------
+// Filter.Fx / Filter.Fi (Filter.py:249-268,279-285): the dense matrices of one predict, materialised
+// from its (full, 85-word) Jacobian record -- the kernels themselves never form them.  One thread per
+// (instance, row).  Layout of the camera rows incl. the reference's column cursor (SURVEY.md App. A.3,
+// Q1): row 18+r: dt at col 3+r | Bm[r] at 6:9 | Cm[r] at 9:15 | 1 at col 16+r; row 21+r: Dm[r][0:3] at
+// 9:12 | Dm[r][3] at col 15 | Em[r] at 19:22 | the 1 of I_24 that survives at (22,22), (23,23).
+// ----------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_jacobians_kernel(int64_t B, const T* __restrict__ J, T* __restrict__ Fx,
+                                                             T* __restrict__ Fi) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= B * 24) return;
+    const int64_t b = tid / 24;
+    const int r = (int)(tid - b * 24);
+    const T* j = J + b * JW;
+    const T dt = j[J_DT];
+    T fx[24], fi[13];
+#pragma unroll
+    for (int c = 0; c < 24; ++c) fx[c] = T(0);
+#pragma unroll
+    for (int c = 0; c < 13; ++c) fi[c] = T(0);
+    if (r < 18) {
+        if (r < 6 || r > 8) fx[r] = T(1);
+        if (r < 3) fx[3 + r] = dt;                                             // Filter.py:253
+        else if (r < 6) { for (int k = 0; k < 3; ++k) fx[6 + k] = j[J_A + 3 * (r - 3) + k]; }    // Filter.py:254
+        else if (r < 9) { for (int k = 0; k < 3; ++k) fx[6 + k] = j[J_TH + 3 * (r - 6) + k]; }   // Filter.py:255
+        else if (r == 15 || r == 16) fx[r + 1] += dt;                          // Filter.py:256-257
+        if (r >= 3 && r < 15) fi[r - 3] = T(1);                                // Filter.py:263
+        if (r == 17) fi[12] = T(1);                                            // Filter.py:264
+    } else if (r < 21) {
+        const int q = r - 18;
+        fx[3 + q] = dt;
+        for (int k = 0; k < 3; ++k) fx[6 + k] = j[J_BM + 3 * q + k];
+        for (int k = 0; k < 6; ++k) fx[9 + k] = j[J_CM + 6 * q + k];
+        fx[16 + q] = T(1);
+        for (int k = 0; k < 3; ++k) fi[3 + k] = j[J_N6 + 3 * q + k];
+    } else {
+        const int q = r - 21;
+        for (int k = 0; k < 3; ++k) fx[9 + k] = j[J_DM + 4 * q + k];
+        fx[15] = j[J_DM + 4 * q + 3];
+        for (int k = 0; k < 3; ++k) fx[19 + k] = j[J_EM + 3 * q + k];
+        if (q > 0) fx[21 + q] = T(1);
+        for (int k = 0; k < 3; ++k) fi[3 + k] = j[J_N6 + 9 + 3 * q + k];
+    }
+    T* ox = Fx + (b * 24 + r) * 24;
+    T* oi = Fi + (b * 24 + r) * 13;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) ox[c] = fx[c];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) oi[c] = fi[c];
+}
+
 // ----------------------------------------------------------------------------------
 // host-side launchers
 // ----------------------------------------------------------------------------------
@@ -2257,7 +2351,7 @@ template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    const size_t stage_bytes = (size_t)64 * ((prm.q_gyro ? J_FULL : J_CORE) + 9) * sizeof(T);   // + parked measurement
+    const size_t stage_bytes = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + 9) * sizeof(T);    // + parked measurement
     hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -2349,6 +2443,31 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
         hipLaunchKernelGGL(eskf_imu_kernel<double>, dim3(blocks), dim3(256), 0, stream, a, make_dev_params<double>(hp));
     else
         hipLaunchKernelGGL(eskf_imu_kernel<float>, dim3(blocks), dim3(256), 0, stream, a, make_dev_params<float>(hp));
+    return hipGetLastError();
+}
+
+hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double* cam6, const double* imu6, void* mse,
+                             hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    MseRef r;
+    for (int i = 0; i < 6; ++i) { r.v[i] = cam6[i]; r.v[6 + i] = imu6 ? imu6[i] : 0.0; }
+    r.has_imu = imu6 ? 1 : 0;
+    const unsigned blocks = (unsigned)((B + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(eskf_update_mse_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, (const double*)xs, r, (double*)mse);
+    else
+        hipLaunchKernelGGL(eskf_update_mse_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)xs, r, (float*)mse);
+    return hipGetLastError();
+}
+
+hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, hipStream_t stream) {
+    if (B <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((B * 24 + 255) / 256);
+    const size_t off = (size_t)ip * (size_t)B * JW;
+    if (dtype == 0)
+        hipLaunchKernelGGL(eskf_jacobians_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, (const double*)J + off, (double*)Fx, (double*)Fi);
+    else
+        hipLaunchKernelGGL(eskf_jacobians_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)J + off, (float*)Fx, (float*)Fi);
     return hipGetLastError();
 }
 

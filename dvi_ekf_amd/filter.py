@@ -59,10 +59,10 @@ class Filter:
         self.H = np.zeros([self.num_meas, ErrorState.SIZE])
         self.H[0:6, 18:24] = np.eye(6)
         self.H[6, 15] = 1
-        # the transition / noise Jacobians are formed block-wise in registers by the kernel
-        # and never materialised
-        self.Fx = None
-        self.Fi = None
+        # the kernels form the transition / noise Jacobians block-wise and never materialise them; the
+        # reference's Fx / Fi attributes (Filter.py:259,265) are expanded on request from the blocks the
+        # last predict left in the workspace (dvi_eskf_get_jacobians)
+        self._dev.keep_jacobians(True)
 
         self.traj = FilterTraj("kf")
         self.traj.append_row(self._log_row(self._config.min_t))
@@ -78,6 +78,23 @@ class Filter:
     def _log_row(self, t: float) -> np.ndarray:
         """The 30-column FilterTraj row of instance 0 (FilterTraj.py:12-41), formed on the device."""
         return self._dev.log_rows(t)[0].cpu().numpy()
+
+    @property
+    def Fx(self) -> Optional[np.ndarray]:
+        """Error-state transition of the last ``propagate`` (24x24, instance 0; Filter.py:249-259,279-285);
+        ``None`` before the first one."""
+        return self._jacobians()[0]
+
+    @property
+    def Fi(self) -> Optional[np.ndarray]:
+        """Noise Jacobian of the last ``propagate`` (24x13, instance 0; Filter.py:261-265,334-342)."""
+        return self._jacobians()[1]
+
+    def _jacobians(self):
+        if not getattr(self, "_propagated", False):
+            return None, None
+        Fx, Fi = self._dev.jacobians()
+        return Fx[0].cpu().numpy(), Fi[0].cpu().numpy()
 
     @property
     def _states(self) -> State:
@@ -201,6 +218,7 @@ class Filter:
     def propagate(self, t, om, acc) -> None:
         """Filter.propagate (Filter.py:219-230) -- one kernel launch."""
         self._dev.predict(self._dt, np.asarray(om, dtype=float), np.asarray(acc, dtype=float))
+        self._propagated = True
         self.traj.append_row(self._log_row(t))
 
     def update(self, t: float, camera, ang_notch: float):
@@ -219,16 +237,36 @@ class Filter:
 
     # -- metrics (host side, Filter.py:397-455) -------------------------------------------------
     def calculate_update_mse(self, i_cam, camera) -> None:
+        """Filter.calculate_update_mse (Filter.py:397-418), reduced on the device from the state record
+        (``dvi_eskf_update_mse``: every instance at once; ``update_mse`` is instance 0's, ``update_mse_batch``
+        the device vector)."""
         cam_reference = camera.rotated if camera.rotated else camera
-        sum_res_cam = 0.0
+        tr = cam_reference.traj
+        cam6 = [float(np.asarray(getattr(tr, c))[i_cam]) for c in ("x", "y", "z", "rx_deg", "ry_deg", "rz_deg")]
+        imu6 = None
+        if self.imu.ref is not None and self.imu.ref.num_values:
+            imu6 = [float(getattr(self.imu.ref, c)[-1]) for c in self.traj.labels_imu[3:9]]
+        self.update_mse_batch = self._dev.update_mse(cam6, imu6)
+        self.update_mse = float(self.update_mse_batch[0])
+
+    def calculate_metric(self, i_cam, camera) -> float:
+        """Filter.calculate_metric (Filter.py:420-450; unused by v1's run loop, Filter.py:167-168): the
+        squared pose errors of the rows at the update indices, averaged over 12 states and the frames,
+        plus the DOF metric.  Host side, from the trajectory log."""
+        cam_reference = camera.rotated if camera.rotated else camera
+        n_if = int(self._config.interframe_vals)
+        upd = list(range(0, len(self.traj.t), n_if))
+        sum_cam = 0.0
         for compc in self.traj.labels_camera[0:6]:
-            ref = getattr(cam_reference.traj, compc[:-1])
-            sum_res_cam += np.square(np.asarray(ref)[i_cam] - getattr(self.traj, compc)[-1])
-        sum_res_imu = 0.0
+            ref = np.asarray(getattr(cam_reference.traj, compc[:-1]))[: i_cam + 1]
+            sum_cam += float(np.sum(np.square(ref - np.asarray(getattr(self.traj, compc))[upd])))
+        sum_imu = 0.0
         if self.imu.ref is not None and self.imu.ref.num_values:
             for comp in self.traj.labels_imu[3:9]:
-                sum_res_imu += np.square(getattr(self.traj, comp)[-1] - getattr(self.imu.ref, comp)[-1])
-        self.update_mse = (sum_res_cam + sum_res_imu) / 12
+                a = np.asarray(getattr(self.traj, comp))[upd[:-1]]
+                r = np.asarray(getattr(self.imu.ref, comp))[upd[:-1]]
+                sum_imu += float(np.sum(np.square(a - r)))
+        return (sum_cam + sum_imu) / (12 * len(upd)) + self.calculate_dof_metric()
 
     def calculate_dof_metric(self) -> float:
         res = self._states.dofs - np.asarray(self._config.gt_imu_dofs, dtype=float)

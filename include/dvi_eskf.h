@@ -17,6 +17,22 @@
  *    distinct handles are independent.
  *  - state vector x26 = p(3) v(3) q(xyzw 4) dofs(6) notch(3) p_cam(3) q_cam(xyzw 4)
  *    (dvi_ekf/filter/state.py:11-86); error state = 24 (state.py:89-129).
+ *  - behaviour: the arithmetic is that of the v1 source including its quirks Q1-Q10 of SURVEY.md
+ *    App. A.6 (column cursor of the camera rows, v_tr := p_tr, Jacobians at n = sigma, half-angle
+ *    residual, stale R_WB_old, ...), which are NOT switchable: the reference's saved trajectory pins
+ *    every one of them.  The only plumbing switch is dvi_eskf_params.hold_frozen (G1).
+ *
+ * HIP graphs.  predict / update / step / epoch / step_from / run_epochs / flush / get_* / copy_state only
+ * enqueue kernels and async copies on `stream` and may be recorded with hipStreamBeginCapture and
+ * replayed any number of times: whether an update's error injection is still due is kept on the DEVICE
+ * (a bit of the per-instance status word), not in the handle, so a replayed sequence continues from
+ * whatever the previous replay left behind exactly as the same calls made eagerly would.  Three rules:
+ *  (1) an epoch longer than any the handle has run needs a larger workspace -- an allocation, which a
+ *      capturing stream cannot do: call dvi_eskf_reserve(h, n_pred) (or run one such epoch) before the
+ *      capture, else the call returns DVI_ESKF_ECAPTURE and nothing is recorded;
+ *  (2) create, clone, destroy, set_noise*, reserve, imu_synthesize and randn allocate or synchronise: not
+ *      capturable;
+ *  (3) pointers recorded in a graph (inputs, K_out, status, handles) must stay valid for its replays.
  */
 #ifndef DVI_ESKF_H
 #define DVI_ESKF_H
@@ -40,6 +56,8 @@ extern "C" {
 #define DVI_ESKF_ENODEV (-2)    /* no usable HIP device                                         */
 #define DVI_ESKF_ENOMEM (-3)    /* device allocation failed                                     */
 #define DVI_ESKF_EHIP (-4)      /* a HIP runtime call / kernel launch failed                    */
+#define DVI_ESKF_ECAPTURE (-5)  /* the stream is being captured into a HIP graph and the call would
+                                   have to allocate or synchronise (see "HIP graphs" below)      */
 
 /* per-instance status word written by update / step */
 #define DVI_ESKF_STATUS_SINGULAR 1  /* innovation covariance not factorisable: state and P left
@@ -90,7 +108,9 @@ int dvi_eskf_set_noise(dvi_eskf* h, const double* Q13x13, const double* R7x7);
  * candidate per instance).  HOST arrays: q13 [B,13] = diag(Q) and r7 [B,7] = diag(R) per instance
  * (Filter.py:67-75,110-117), sigma_om3 [B,3] = the gyro noise std-dev at which the Jacobians are
  * evaluated (Filter.py:330-333) or NULL to keep the one of dvi_eskf_create.  Steps then run through
- * the LDS-image covariance kernel; dvi_eskf_set_noise returns to one model for the whole batch. */
+ * the per-instance-noise build of the selected covariance kernel (row-resident by default: it reads the
+ * instance's 24-word noise record next to the residual); dvi_eskf_set_noise returns to one model for
+ * the whole batch.  Copies and synchronises: not capturable. */
 int dvi_eskf_set_noise_per_instance(dvi_eskf* h, const double* q13, const double* r7, const double* sigma_om3,
                                     void* stream);
 
@@ -178,8 +198,24 @@ int dvi_eskf_gather_calibration(dvi_eskf* h, void* dofs_all, void* rccl_comm, vo
 /* The error injection of an update (state.py:46-60) is deferred: it is applied by the next
  * predict/update/step/epoch call, or by any call that reads or replaces the state (get_state,
  * set_state, get_calibration, clone, copy_state).  dvi_eskf_flush applies it explicitly -- needed
- * only before looking at dvi_eskf_raw_x(). */
+ * only before looking at dvi_eskf_raw_x().  Which instances still await their injection is device
+ * state, so all of this also holds across HIP-graph replays (see "HIP graphs" above). */
 int dvi_eskf_flush(dvi_eskf* h, void* stream);
+
+/* Sizes the per-handle workspace for epochs of up to n_pred predicts (one Jacobian record per predict
+ * and instance).  Optional -- epoch / run_epochs grow it on demand -- except before capturing such an
+ * epoch into a HIP graph.  Allocates and synchronises the device. */
+int dvi_eskf_reserve(dvi_eskf* h, int n_pred);
+
+/* Filter.Fx / Filter.Fi (Filter.py:249-268; filled by _cam_error_jacobian, Filter.py:279-285,334-342): the
+ * dense 24x24 error-state transition and 24x13 noise Jacobian of the LAST predict, per instance.  The
+ * kernels never form these matrices; with dvi_eskf_keep_jacobians(h, 1) every predict leaves its blocks
+ * (incl. the noise rows, which are otherwise only computed in tune mode) in the workspace and
+ * dvi_eskf_get_jacobians expands them: Fx_out [B,24,24], Fi_out [B,24,13], row-major, handle dtype.
+ * DVI_ESKF_EINVAL when no predict has run since keeping was switched on.  Keeping costs 18 more words
+ * of workspace traffic per predict and instance; off by default. */
+int dvi_eskf_keep_jacobians(dvi_eskf* h, int on);
+int dvi_eskf_get_jacobians(const dvi_eskf* h, void* Fx_out, void* Fi_out, void* stream);
 
 /* Raw device buffers (zero-copy views for profiling / checkpointing): packed lower
  * triangle of P [B,300] and the persistent state block, structure-of-arrays [36,B] with
@@ -193,6 +229,15 @@ void* dvi_eskf_raw_x(dvi_eskf* h);
  * xc yc zc rx_c ry_c rz_c qwc qxc qyc qzc, Euler angles extrinsic xyz in degrees.
  * rows_out [B,30] in the handle's dtype; applies a pending injection first. */
 int dvi_eskf_log_rows(dvi_eskf* h, double t, void* rows_out, void* stream);
+
+/* Filter.calculate_update_mse (Filter.py:397-418), per instance, as a reduction on the device: the mean of
+ * the 12 squared differences between the filter's camera pose (position, extrinsic-xyz Euler angles in
+ * degrees) and the camera frame's, and between the filter's IMU velocity / Euler angles and the IMU
+ * reference sample's.  HOST arrays: cam_ref6 = (x, y, z, rx_deg, ry_deg, rz_deg) of the camera frame
+ * (VisualTraj columns, Filter.py:402-406), imu_ref6 = (vx, vy, vz, rx, ry, rz) of the last IMU reference
+ * sample (ImuRefTraj columns, Filter.py:409-413) or NULL when no reference trajectory is kept (the IMU half
+ * then contributes 0).  mse_out: device [B] in the handle's dtype.  Applies a pending injection first. */
+int dvi_eskf_update_mse(dvi_eskf* h, const double* cam_ref6, const double* imu_ref6, void* mse_out, void* stream);
 
 /* Input synthesis, the step in front of the path: noise-free IMU samples from the
  * camera trajectory through the probe kinematics -- f_imu_meas / f_imu of

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libeskf_oracle.so")
+_SO_HP = os.path.join(_HERE, "_build", "libeskf_oracle_hp.so")   # __float128 build: the adjudicator
 
 
 class OracleParams(C.Structure):
@@ -22,19 +23,22 @@ class OracleParams(C.Structure):
 
 def build(force: bool = False) -> str:
     src = [os.path.join(_HERE, n) for n in ("eskf_oracle.c", "eskf_oracle.h", "Makefile")]
-    stale = not os.path.exists(_SO) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    stale = any(not os.path.exists(so) or any(os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+                for so in (_SO, _SO_HP))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
+def lib(hp: bool = False):
+    """hp=True: the extended-precision (quad) build of the same source -- same entry points, same double
+    arrays in and out, every intermediate in __float128."""
+    if hp not in _libs:
+        build()
+        _lib = _libs[hp] = C.CDLL(_SO_HP if hp else _SO)
         dp = C.POINTER(C.c_double)
         pp = C.POINTER(OracleParams)
         _lib.eskf_oracle_init_rwb.argtypes = [dp, dp]
@@ -44,7 +48,7 @@ def lib():
         _lib.eskf_oracle_predict_batch.argtypes = [pp, C.c_int64, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp]
         _lib.eskf_oracle_update_batch.argtypes = [pp, C.c_int64, dp, dp, dp, dp, dp, C.POINTER(C.c_int32)]
         _lib.eskf_oracle_num_threads.restype = C.c_int
-    return _lib
+    return _libs[hp]
 
 
 def _p(a):
@@ -65,9 +69,10 @@ def make_params(L, theta_cam, frozen, hold_frozen, sigma_a, sigma_om, Q, R) -> O
 class OracleBatch:
     """B independent filter instances stepped by the C oracle (OpenMP over instances)."""
 
-    def __init__(self, prm: OracleParams, x0, P0, om0, acc0):
+    def __init__(self, prm: OracleParams, x0, P0, om0, acc0, hp: bool = False):
         self.prm = prm
-        self.x = np.ascontiguousarray(np.atleast_2d(np.asarray(x0, dtype=float)))          # [B,26]
+        self.hp = bool(hp)
+        self.x = np.array(np.atleast_2d(np.asarray(x0, dtype=float)), order="C")              # [B,26] (own copy)
         self.B = self.x.shape[0]
         P0 = np.asarray(P0, dtype=float)
         self.P = np.ascontiguousarray(np.broadcast_to(P0, (self.B, 24, 24)).copy())
@@ -75,7 +80,7 @@ class OracleBatch:
         self.acc_old = np.ascontiguousarray(np.broadcast_to(np.asarray(acc0, dtype=float), (self.B, 3)).copy())
         self.Rwb = np.empty((self.B, 9))
         for b in range(self.B):
-            lib().eskf_oracle_init_rwb(_p(self.x[b]), _p(self.Rwb[b]))
+            lib(self.hp).eskf_oracle_init_rwb(_p(self.x[b]), _p(self.Rwb[b]))
         self.status = np.zeros(self.B, dtype=np.int32)
 
     def predict(self, dt, om, acc):
@@ -84,14 +89,14 @@ class OracleBatch:
         acc = np.ascontiguousarray(np.broadcast_to(np.asarray(acc, dtype=float), (self.B, 3)))
         stride = 0 if dt.size == 1 else 1
         assert stride == 0 or dt.size == self.B
-        lib().eskf_oracle_predict_batch(C.byref(self.prm), self.B, _p(self.x), _p(self.P), _p(self.om_old),
+        lib(self.hp).eskf_oracle_predict_batch(C.byref(self.prm), self.B, _p(self.x), _p(self.P), _p(self.om_old),
                                         _p(self.acc_old), _p(self.Rwb), _p(dt), stride, _p(om), _p(acc))
 
     def update(self, pos, quat, notch):
         pos = np.ascontiguousarray(np.broadcast_to(np.asarray(pos, dtype=float), (self.B, 3)))
         quat = np.ascontiguousarray(np.broadcast_to(np.asarray(quat, dtype=float), (self.B, 4)))
         notch = np.ascontiguousarray(np.broadcast_to(np.asarray(notch, dtype=float), (self.B,)))
-        lib().eskf_oracle_update_batch(C.byref(self.prm), self.B, _p(self.x), _p(self.P), _p(pos), _p(quat),
+        lib(self.hp).eskf_oracle_update_batch(C.byref(self.prm), self.B, _p(self.x), _p(self.P), _p(pos), _p(quat),
                                        _p(notch), self.status.ctypes.data_as(C.POINTER(C.c_int32)))
         return self.status
 
@@ -101,7 +106,7 @@ class OracleBatch:
         Fi = np.empty((24, 13))
         om = np.ascontiguousarray(om, dtype=float)
         acc = np.ascontiguousarray(acc, dtype=float)
-        lib().eskf_oracle_predict(C.byref(self.prm), _p(self.x[b]), _p(self.P[b]), _p(self.om_old[b]),
+        lib(self.hp).eskf_oracle_predict(C.byref(self.prm), _p(self.x[b]), _p(self.P[b]), _p(self.om_old[b]),
                                   _p(self.acc_old[b]), _p(self.Rwb[b]), float(dt), _p(om), _p(acc), _p(Fx), _p(Fi))
         return Fx, Fi
 
@@ -109,7 +114,7 @@ class OracleBatch:
         K = np.empty((24, 7))
         pos = np.ascontiguousarray(pos, dtype=float)
         quat = np.ascontiguousarray(quat, dtype=float)
-        st = lib().eskf_oracle_update(C.byref(self.prm), _p(self.x[b]), _p(self.P[b]), _p(pos), _p(quat),
+        st = lib(self.hp).eskf_oracle_update(C.byref(self.prm), _p(self.x[b]), _p(self.P[b]), _p(pos), _p(quat),
                                       float(notch), _p(K))
         return st, K
 

@@ -87,3 +87,43 @@ def test_update_returns_gain_and_deepcopy_is_independent(tmp_path):
     assert np.array_equal(K, K2)
     assert kf.states_batch.shape == (3, 26) and np.array_equal(kf.states_batch[0], kf.states_batch[2])
     assert kf.calculate_dof_metric_batch().shape == (3,)
+
+
+def test_update_mse_is_a_device_reduction_and_filter_exposes_fx_fi(tmp_path):
+    """Filter.calculate_update_mse (Filter.py:397-418) comes from dvi_eskf_update_mse -- checked against the
+    reference's formula evaluated on the trajectory log --, and Filter.Fx / Filter.Fi (Filter.py:259,265) are
+    the dense Jacobians of the last propagate (against the oracle)."""
+    from dvi_ekf_amd import Simulator
+    from oracle import c_oracle
+    from tests.helpers import default_run
+    cfg = _config(tmp_path, False, batch=4)
+    sim = Simulator(cfg)
+    kf, cam = sim.kf, sim.camera
+    assert kf.Fx is None and kf.Fi is None                           # nothing propagated yet
+    c, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True)
+    prm = c_oracle.make_params(c.model.length, c.model.angle, c.frozen_dofs, False, sa, so, Q, R)
+    o = c_oracle.OracleBatch(prm, ri.x0[None, :], ri.P0, ri.om0, ri.acc0)
+    old_t, ip = cfg.min_t, 0
+    for i_cam in range(1, 4):
+        t = cam.t[i_cam]
+        kf.propagate_imu(old_t, t)
+        for _ in range(ri.n_pred[i_cam - 1]):
+            Fxo, Fio = o.predict_one(0, ri.dt[ip], ri.om[ip], ri.acc[ip])
+            ip += 1
+        assert kf.Fx.shape == (24, 24) and kf.Fi.shape == (24, 13)
+        assert np.abs(kf.Fx - Fxo).max() <= 1e-12 * max(1.0, np.abs(Fxo).max())
+        assert np.abs(kf.Fi - Fio).max() <= 1e-12 * max(1.0, np.abs(Fio).max())
+        kf.update(t, cam.traj.at_index(i_cam), cam.get_notch_vec_at(i_cam)[0])
+        o.update(ri.pos[i_cam - 1], ri.quat[i_cam - 1], ri.notch[i_cam - 1])
+        kf.calculate_update_mse(i_cam, cam)
+        # the reference's loops over the log columns (Filter.py:401-416)
+        s_cam = sum((np.asarray(getattr(cam.traj, lab[:-1]))[i_cam] - getattr(kf.traj, lab)[-1]) ** 2
+                    for lab in kf.traj.labels_camera[0:6])
+        s_imu = sum((getattr(kf.traj, lab)[-1] - getattr(kf.imu.ref, lab)[-1]) ** 2 for lab in kf.traj.labels_imu[3:9])
+        want = (s_cam + s_imu) / 12
+        assert kf.update_mse == pytest.approx(want, rel=1e-9, abs=1e-15)
+        assert kf.update_mse_batch.shape == (4,) and bool((kf.update_mse_batch == kf.update_mse_batch[0]).all())
+        old_t = t
+    assert kf.update_mse > 0
+    m = kf.calculate_metric(3, cam)
+    assert np.isfinite(m) and m >= kf.calculate_dof_metric()

@@ -35,10 +35,11 @@ def _make(cfg, ri, Q, R, sa, so, B, hold, x0=None, dtype=None, lpi=None):
     return f
 
 
-def _oracle(cfg, ri, Q, R, sa, so, B, hold, x0=None):
+def _oracle(cfg, ri, Q, R, sa, so, B, hold, x0=None, hp=False):
+    """hp=True: the extended-precision (quad) build of the oracle -- the adjudicator"""
     prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, hold, sa, so, Q, R)
     x0 = np.tile(ri.x0, (B, 1)) if x0 is None else x0
-    return c_oracle.OracleBatch(prm, x0, ri.P0, ri.om0, ri.acc0)
+    return c_oracle.OracleBatch(prm, x0, ri.P0, ri.om0, ri.acc0, hp=hp)
 
 
 def _perturbed_x0(ri, B, seed=1000):
@@ -86,25 +87,58 @@ def _innovation_condition(P, R):
     return np.linalg.cond(S * np.outer(d, d)), S
 
 
+# Adjudicated comparison of an update (every instance, whatever its conditioning).  The reference forms
+# K = P H^T inv(S) with an explicit fp64 inverse; for an ill-conditioned S that result is itself far from
+# the exact one, so "equal to the fp64 oracle" stops being the right question.  The __float128 build of
+# the oracle (oracle/eskf_oracle.c, -DESKF_ORACLE_QUAD) gives the exact result of the reference's
+# formulas from the same inputs; an fp64 implementation passes when its distance from that is within
+#     FLOOR + C_ADJ * (distance of the literal fp64 oracle from it)
+# -- i.e. it is allowed to be as inaccurate as the reference's own arithmetic (times a fixed small
+# factor) and never more than that; FLOOR is the well-conditioned tolerance of this file's header.
+C_ADJ = 2.0
+FLOOR_X, FLOOR_P = 1e-11, 1e-10
+
+
+def _rel_rows(a, b):
+    """per instance: max |a - b| / max(1, |b|)"""
+    B = a.shape[0]
+    a, b = np.asarray(a).reshape(B, -1), np.asarray(b).reshape(B, -1)
+    return np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
+
+
+def adjudicate(x_gpu, P_gpu, o, h):
+    """o: fp64 oracle after the update, h: quad oracle after the same update from the same input.
+    Returns per-instance (x excess, P excess, x error of the GPU, x error of the fp64 oracle); an
+    excess <= 0 passes."""
+    ex_g, ex_r = _rel_rows(x_gpu, h.x), _rel_rows(o.x, h.x)
+    eP_g, eP_r = _rel_rows(P_gpu, h.P), _rel_rows(o.P, h.P)
+    return ex_g - (FLOOR_X + C_ADJ * ex_r), eP_g - (FLOOR_P + C_ADJ * eP_r), ex_g, ex_r, eP_g, eP_r
+
+
 @pytest.mark.parametrize("golden,frozen,nframes", [(False, (0,) * 6, 30), (False, (1,) * 6, 12), (True, (0,) * 6, 20),
                                                    (False, (1, 0, 1, 0, 0, 1), 12)])
 def test_forced_single_step_parity(golden, frozen, nframes):
-    """Every predict and every update starts from the oracle's state on both sides.
+    """Every predict and every update starts from the oracle's state on both sides.  EVERY update of
+    EVERY instance is checked, through both covariance kernels (the row-resident one the benchmark times
+    and the LDS-image one that also forms the gain matrix):
 
-    The reference computes K = P H^T inv(S) with an explicit inverse; once its own
-    dynamics have blown the covariance up (golden-compat 1:1 schedule with unfrozen DOFs,
-    frame 9 onwards: |x| ~ 1e3, equilibrated cond(S) > 1e4) that K is only accurate to
-    ~cond * eps and stops being a meaningful target.  Instances in that state are
-    checked for backward stability (K S = P H^T) instead of against the oracle."""
+      * equilibrated cond(S) <= 1e4: against the fp64 oracle, tolerances of the header;
+      * all of them, ill-conditioned ones included (golden-compat 1:1 schedule with unfrozen DOFs, frame 9
+        onwards: |x| ~ 1e3, cond(S) up to 1e6 equilibrated, 1e10 raw): against the extended-precision
+        adjudicator, see ``adjudicate`` -- no instance is skipped;
+      * the gain matrix: backward stability K S = P H^T everywhere, and against the oracle's K where
+        cond(S) <= 1e4."""
     B = 16
     cfg, ri, Q, R, sa, so = default_run(golden_compat=golden, fast=False, frozen=frozen,
                                         interframe=(1 if golden else None))
     x0 = _perturbed_x0(ri, B)
     f = _make(cfg, ri, Q, R, sa, so, B, golden, x0)
     o = _oracle(cfg, ri, Q, R, sa, so, B, golden, x0)
+    h = _oracle(cfg, ri, Q, R, sa, so, B, golden, x0, hp=True)
     q_old = o.x[:, 6:10].copy()
     ip = 0
     ex = eP = eK = eres = 0.0
+    worst = {"x_excess": -1.0, "P_excess": -1.0, "x_gpu": 0.0, "x_ref": 0.0, "P_gpu": 0.0, "P_ref": 0.0, "kappa": 0.0}
     n_cmp = n_all = 0
     for k in range(nframes):
         for _ in range(ri.n_pred[k]):
@@ -120,9 +154,7 @@ def test_forced_single_step_parity(golden, frozen, nframes):
             assert np.abs(s["q_old"] - o.x[:, 6:10]).max() < 1e-14
         P_in = o.P.copy()
         f.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old)
-        # the update runs twice: through the default (row-resident) kernel, and -- on a clone -- with
-        # the gain matrix requested, which is served by the LDS-image kernel; both are held to
-        # the oracle
+        h.x[:], h.P[:] = o.x, o.P                       # the adjudicator starts from the same input
         g = f.clone()
         st, _ = f.update(ri.pos[k], ri.quat[k], ri.notch[k])
         stg, K = g.update(ri.pos[k], ri.quat[k], ri.notch[k], want_gain=True)
@@ -130,21 +162,35 @@ def test_forced_single_step_parity(golden, frozen, nframes):
         assert (st.cpu().numpy() == 0).all() and (stg.cpu().numpy() == 0).all()
         s = {k_: v.cpu().numpy() for k_, v in f.get_state().items()}
         sg = {k_: v.cpu().numpy() for k_, v in g.get_state().items()}
+        Ko = np.empty((B, 24, 7))
         for b in range(B):
-            sb, Ko = o.update_one(b, ri.pos[k], ri.quat[k], ri.notch[k])
+            sb, Ko[b] = o.update_one(b, ri.pos[k], ri.quat[k], ri.notch[k])
             assert sb == 0
-            kappa, S = _innovation_condition(P_in[b], R)
+        assert (h.update(ri.pos[k], ri.quat[k], ri.notch[k]) == 0).all()
+        kappa = np.array([_innovation_condition(P_in[b], R)[0] for b in range(B)])
+        for name, sk in (("rows", s), ("lds", sg)):
+            xe, Pe, xg, xr, Pg, Pr = adjudicate(sk["x"], sk["P"], o, h)
+            i = int(np.argmax(xe))
+            if xe[i] > worst["x_excess"]:
+                worst.update(x_excess=xe[i], x_gpu=xg[i], x_ref=xr[i], kappa=kappa[i])
+            j = int(np.argmax(Pe))
+            if Pe[j] > worst["P_excess"]:
+                worst.update(P_excess=Pe[j], P_gpu=Pg[j], P_ref=Pr[j])
+            assert xe.max() <= 0 and Pe.max() <= 0, (name, k, xe.max(), Pe.max(), xg[i], xr[i], Pg[j], Pr[j], kappa[i])
+        for b in range(B):
+            S = P_in[b][np.ix_(SEL, SEL)] + R
             PH = P_in[b][:, SEL]
             eres = max(eres, (np.abs(K[b] @ S - PH) / (np.abs(K[b]) @ np.abs(S) + np.abs(PH) + 1e-300)).max())
             n_all += 1
-            if kappa <= 1e4:
+            if kappa[b] <= 1e4:
                 n_cmp += 1
                 ex = max(ex, _rel(s["x"][b], o.x[b], 1), _rel(sg["x"][b], o.x[b], 1))
                 eP = max(eP, _rel(s["P"][b], o.P[b], 1), _rel(sg["P"][b], o.P[b], 1))
-                eK = max(eK, _rel(K[b], Ko, 1))
+                eK = max(eK, _rel(K[b], Ko[b], 1))
     print(f"forced parity golden={golden} frozen={frozen}: x {ex:.2e}  P {eP:.2e}  K {eK:.2e}  "
-          f"solve residual {eres:.2e}  compared {n_cmp}/{n_all} updates")
-    assert n_cmp >= 0.4 * n_all
+          f"solve residual {eres:.2e}  well-conditioned {n_cmp}/{n_all} updates; adjudicated all {n_all}: "
+          f"closest call x: gpu {worst['x_gpu']:.1e} vs fp64 oracle {worst['x_ref']:.1e} from exact (cond {worst['kappa']:.1e}), "
+          f"P: gpu {worst['P_gpu']:.1e} vs {worst['P_ref']:.1e}")
     assert ex <= 1e-11 and eP <= 1e-10 and eK <= 1e-8 and eres <= 1e-10
 
 
@@ -393,6 +439,63 @@ def test_fp32_variant_tracks_oracle_loosely():
     s = f.get_state()
     assert np.abs(s["x"].cpu().numpy() - o.x).max() <= 2e-5 * np.abs(o.x).max()
     assert np.abs(s["P"].cpu().numpy() - o.P).max() <= 2e-4 * np.abs(o.P).max()
+
+
+# Stated fp32 tolerances of the update / pair-step (measured on MI355X): a forced single
+# step from the fp64 oracle's state, relative to the instance's magnitude.  fp32 keeps 7 digits and the
+# update subtracts K S K^T from a P that shrinks by up to ten orders of magnitude in its measured block
+# (R_theta ~ 3e-14 against a prior of 1e-5), so the covariance tolerance is set by the LARGEST entry of P.
+FP32_UPDATE_TOL_X, FP32_UPDATE_TOL_P = 5e-4, 5e-3
+
+
+@pytest.mark.parametrize("golden,frozen,lpi", [(False, (0,) * 6, None), (False, (1,) * 6, None), (True, (0,) * 6, None),
+                                               (False, (0,) * 6, 32)])
+def test_fp32_forced_single_step_update_parity(golden, frozen, lpi):
+    """The fp32 update (BASELINE configs #3/#5 compute in fp32) against the fp64 oracle: every update, the
+    predicts of an epoch and the fused predict+update pair start from the oracle's state rounded to fp32.
+    The row-resident kernel processes the seven measurements one after the other, i.e. every pivot is a scalar
+    division -- no 7x7 factorisation whose scaling (R_theta ~ 3e-14 next to R_p ~ 4e-4) would need
+    equilibrating; what limits fp32 is the cancellation P - K S K^T, stated above."""
+    B = 16
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=golden, fast=False, frozen=frozen, interframe=(1 if golden else None))
+    x0 = _perturbed_x0(ri, B)
+    f = _make(cfg, ri, Q, R, sa, so, B, golden, x0, dtype=torch.float32, lpi=lpi)
+    o = _oracle(cfg, ri, Q, R, sa, so, B, golden, x0)
+    q_old = o.x[:, 6:10].copy()
+    ip = 0
+    ex_u = eP_u = ex_p = eP_p = ex_s = eP_s = 0.0
+    relP = lambda a, b: (np.abs(a - b).reshape(B, -1).max(axis=1) / np.abs(b).reshape(B, -1).max(axis=1)).max()
+    for k in range(8):
+        xin, Pin, oin, ain, qin = o.x.copy(), o.P.copy(), o.om_old.copy(), o.acc_old.copy(), q_old.copy()
+        n = int(ri.n_pred[k])
+        for _ in range(n):
+            f.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old)
+            f.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            o.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
+            q_old = o.x[:, 6:10].copy()
+            ip += 1
+            s = f.get_state(("x", "P"))
+            ex_p = max(ex_p, _rel(s["x"].double().cpu().numpy(), o.x, B))
+            eP_p = max(eP_p, relP(s["P"].double().cpu().numpy(), o.P))
+        f.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old)
+        st, _ = f.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        o.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        assert (st.cpu().numpy() == 0).all()
+        s = f.get_state(("x", "P"))
+        ex_u = max(ex_u, _rel(s["x"].double().cpu().numpy(), o.x, B))
+        eP_u = max(eP_u, relP(s["P"].double().cpu().numpy(), o.P))
+        # the same frame as ONE launch (epoch: n predicts + update) from the frame's input
+        f.set_state(x=xin, P=Pin, om_old=oin, acc_old=ain, q_old=qin)
+        st, _ = f.epoch(ri.dt[ip - n:ip], ri.om[ip - n:ip], ri.acc[ip - n:ip], ri.pos[k], ri.quat[k], ri.notch[k])
+        assert (st.cpu().numpy() == 0).all()
+        s = f.get_state(("x", "P"))
+        ex_s = max(ex_s, _rel(s["x"].double().cpu().numpy(), o.x, B))
+        eP_s = max(eP_s, relP(s["P"].double().cpu().numpy(), o.P))
+    print(f"fp32 forced single step (golden={golden}, frozen={frozen[0]}, lanes={lpi}): predict x {ex_p:.1e} P {eP_p:.1e} | "
+          f"update x {ex_u:.1e} P {eP_u:.1e} | fused epoch x {ex_s:.1e} P {eP_s:.1e}")
+    assert ex_p <= 2e-5 and eP_p <= 2e-4
+    assert ex_u <= FP32_UPDATE_TOL_X and eP_u <= FP32_UPDATE_TOL_P
+    assert ex_s <= FP32_UPDATE_TOL_X and eP_s <= FP32_UPDATE_TOL_P
 
 
 @pytest.mark.parametrize("lpi", [None, 2, 32])

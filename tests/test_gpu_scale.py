@@ -45,7 +45,15 @@ def test_config2_and_4_full_batch_identical_instances_and_symmetry():
 
 def test_config2_batch1024_perturbed_instances_vs_oracle():
     """config #2: B = 1024, fp64, 1:1 pairs; instance 0 = the reference run, the others start from
-    perturbed extrinsic DOFs (unfrozen); 8 pair-steps free-running; all 1024 instances vs oracle."""
+    perturbed extrinsic DOFs (unfrozen); 8 pair-steps.
+
+    EVERY instance is checked on EVERY pair-step: the oracle runs free, and each pair-step of the GPU
+    starts from the oracle's state (forced step) and is adjudicated by the extended-precision build of
+    the oracle (tests/test_gpu_parity.py::adjudicate) -- also the instances whose state the reference
+    filter itself has blown up (|x| > 100 for about half of them after 8 pairs; DESIGN.md, Numerical
+    behaviour), for which the fp64 oracle alone is not a usable truth.  A second GPU filter runs free and
+    must follow the oracle to 1e-9 wherever the reference filter is still in its physical range."""
+    from tests.test_gpu_parity import adjudicate
     B = 1024
     cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=False, frozen=(0,) * 6, interframe=1)
     rng = np.random.default_rng(1000)
@@ -53,26 +61,43 @@ def test_config2_batch1024_perturbed_instances_vs_oracle():
     x0[1:, 10:16] += rng.normal(0, 1, (B - 1, 6)) * np.sqrt(np.diag(ri.P0)[9:15])
     f = _filter(cfg, Q, R, sa, so, B, True)
     f.set_state(x=x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    forced = _filter(cfg, Q, R, sa, so, B, True)
     prm = c_oracle.make_params(cfg.model.length, cfg.model.angle, cfg.frozen_dofs, True, sa, so, Q, R)
     o = c_oracle.OracleBatch(prm, x0, ri.P0, ri.om0, ri.acc0)
+    h = c_oracle.OracleBatch(prm, x0, ri.P0, ri.om0, ri.acc0, hp=True)
     sane = np.ones(B, dtype=bool)
     worst = 0.0
+    closest = (0.0, 0.0)
+    q_old = o.x[:, 6:10].copy()
     for k in range(8):
         f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
-        o.predict(ri.dt[k], ri.om[k], ri.acc[k])
-        o.update(ri.pos[k], ri.quat[k], ri.notch[k])
-        # the reference filter itself blows up for some perturbed instances on this schedule
-        # (Numerical behaviour): once an instance's state has left the physical range
-        # its trajectory amplifies rounding differences and is no longer a target
+        forced.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old)
+        h.x[:], h.P[:], h.om_old[:], h.acc_old[:], h.Rwb[:] = o.x, o.P, o.om_old, o.acc_old, o.Rwb
+        st, _ = forced.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
+        for orc in (o, h):
+            orc.predict(ri.dt[k], ri.om[k], ri.acc[k])
+        q_old = o.x[:, 6:10].copy()
+        # (the adjudicated quantity is the whole pair-step from the common input: the quad oracle's
+        #  update sees the quad prediction, the fp64 oracle's and the GPU's see their own)
+        for orc in (o, h):
+            orc.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        assert int(st.abs().max()) == 0
+        s = forced.get_state(("x", "P"))
+        xe, Pe, xg, xr, Pg, Pr = adjudicate(s["x"].cpu().numpy(), s["P"].cpu().numpy(), o, h)
+        i = int(np.argmax(xe))
+        assert xe.max() <= 0 and Pe.max() <= 0, (k, i, xe.max(), Pe.max(), xg[i], xr[i])
+        if xg.max() > closest[0]:
+            closest = (float(xg.max()), float(xr[int(np.argmax(xg))]))
         sane &= np.abs(o.x).max(axis=1) < 100.0
         x = f.x.cpu().numpy()
         err = np.abs(x - o.x).max(axis=1) / np.maximum(1.0, np.abs(o.x).max(axis=1))
         if k < 5:
             worst = max(worst, err[sane].max())
-    print(f"config #2: {sane.sum()} of {B} instances stay in range over 8 pairs; "
-          f"max rel |dx| of those over the first 5 pairs = {worst:.2e}; instance 0 after 8 pairs = {err[0]:.1e}")
-    assert sane[0] and err[0] <= 1e-9          # the unperturbed reference run
-    assert sane.sum() >= 0.5 * B and worst <= 1e-9
+    print(f"config #2: all {B} instances adjudicated on all 8 pair-steps (largest GPU distance from exact "
+          f"{closest[0]:.1e}, fp64 oracle there {closest[1]:.1e}); free-running: {sane.sum()} of {B} stay in range over "
+          f"8 pairs, max rel |dx| of those over the first 5 pairs = {worst:.2e}; instance 0 after 8 pairs = {err[0]:.1e}")
+    assert sane[0] and err[0] <= 1e-9          # the unperturbed reference run, free-running
+    assert worst <= 1e-9
 
 
 def test_config3_predict_only_fp32_one_million_instances():
