@@ -54,7 +54,12 @@ class Filter:
         self.update_noise_matrices()
 
         # state, covariance and buffers live on the device (Filter.py:44-45,78-80)
-        self._dev.set_state(x=self._x0.vector, P=cov0, om_old=self.imu.om.squeeze(), acc_old=self.imu.acc.squeeze())
+        # (the sample eval_init has just appended, i.e. the last column: identical to the reference's
+        #  ``imu.om.squeeze()`` (Filter.py:78-79) for a first construction; for a re-construction by
+        #  Simulator.reset_kf (Simulator.py:160-161) the reference's squeeze yields a 3x2 buffer that fails at the
+        #  next propagate -- here the tuning loop can re-create the filter)
+        self._dev.set_state(x=self._x0.vector, P=cov0, om_old=np.asarray(self.imu.om).reshape(3, -1)[:, -1],
+                            acc_old=np.asarray(self.imu.acc).reshape(3, -1)[:, -1])
 
         self.H = np.zeros([self.num_meas, ErrorState.SIZE])
         self.H[0:6, 18:24] = np.eye(6)

@@ -53,7 +53,7 @@ def test_config2_batch1024_perturbed_instances_vs_oracle():
     filter itself has blown up (|x| > 100 for about half of them after 8 pairs; DESIGN.md, Numerical
     behaviour), for which the fp64 oracle alone is not a usable truth.  A second GPU filter runs free and
     must follow the oracle to 1e-9 wherever the reference filter is still in its physical range."""
-    from tests.test_gpu_parity import adjudicate
+    from tests.test_gpu_parity import adjudicate, innovation_conditions
     B = 1024
     cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=False, frozen=(0,) * 6, interframe=1)
     rng = np.random.default_rng(1000)
@@ -77,15 +77,16 @@ def test_config2_batch1024_perturbed_instances_vs_oracle():
         for orc in (o, h):
             orc.predict(ri.dt[k], ri.om[k], ri.acc[k])
         q_old = o.x[:, 6:10].copy()
+        kappa = innovation_conditions(o.P, R)
         # (the adjudicated quantity is the whole pair-step from the common input: the quad oracle's
         #  update sees the quad prediction, the fp64 oracle's and the GPU's see their own)
         for orc in (o, h):
             orc.update(ri.pos[k], ri.quat[k], ri.notch[k])
         assert int(st.abs().max()) == 0
         s = forced.get_state(("x", "P"))
-        xe, Pe, xg, xr, Pg, Pr = adjudicate(s["x"].cpu().numpy(), s["P"].cpu().numpy(), o, h)
+        xe, Pe, xg, xr, Pg, Pr = adjudicate(s["x"].cpu().numpy(), s["P"].cpu().numpy(), o, h, kappa)
         i = int(np.argmax(xe))
-        assert xe.max() <= 0 and Pe.max() <= 0, (k, i, xe.max(), Pe.max(), xg[i], xr[i])
+        assert xe.max() <= 0 and Pe.max() <= 0, f"pair {k} instance {i}: x gpu {xg[i]:.1e} ref {xr[i]:.1e} cond {kappa[i]:.1e}"
         if xg.max() > closest[0]:
             closest = (float(xg.max()), float(xr[int(np.argmax(xg))]))
         sane &= np.abs(o.x).max(axis=1) < 100.0
