@@ -199,15 +199,19 @@ struct Jac {
 // NOMINAL = false: only what the Jacobians of the following steps depend on is advanced
 // (attitude q, dofs, notch); JAC = false: the blocks are not formed.  The two halves are
 // independent, so the pre kernel gives them to different waves.
-template <typename T, bool NOMINAL = true, bool JAC = true>
+// ATT = false (Jacobian role of a single-predict launch): the attitude is not advanced either -- the blocks of
+// THIS predict only need the buffers (om_old, acc_old, q_old), dofs and notch; q would only matter as the
+// next predict's q_old.
+template <typename T, bool NOMINAL = true, bool JAC = true, bool ATT = true>
 __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& prm, const T* sig_om, T dt,
                                                const T* om_n, const T* acc_n, Jac<T>& J) {
+    static_assert(ATT || (!NOMINAL && JAC), "ATT = false is the Jacobian role only");
     T R[9], Ro[9];
-    quat_to_mat(s.q, R);
+    if (ATT) quat_to_mat(s.q, R);
     if (JAC) quat_to_mat(s.qo, Ro);
 
     // --- nominal state -------------------------------------------------------------
-    {
+    if (ATT) {
         T om_avg[3], w[3], RS[9], Rn[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { om_avg[i] = (s.om_o[i] + om_n[i]) * T(0.5); w[i] = dt * om_avg[i]; }
@@ -252,6 +256,14 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
                 if ((prm.frozen_mask >> i) & 1) s.dofs[i] = T(0);
         }
         mat_to_quat(Rn, s.q);                                                       // state.py:67
+    } else {
+        s.notch[0] += dt * s.notch[1];                                              // equations.py:80-82
+        s.notch[1] += dt * s.notch[2];
+        if (!prm.hold_frozen) {                                                     // Filter.py:243-245
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if ((prm.frozen_mask >> i) & 1) s.dofs[i] = T(0);
+        }
     }
     if (!JAC) {
 #pragma unroll
@@ -371,6 +383,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
                 for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
         }
     }
+    if (!ATT) return;
     // buffer swap (Filter.py:225-227)
 #pragma unroll
     for (int i = 0; i < 3; ++i) { s.om_o[i] = om_n[i]; s.acc_o[i] = acc_n[i]; }
@@ -414,6 +427,19 @@ __device__ __forceinline__ void load_state(const T* xs, int64_t B, int64_t b, St
 #pragma unroll
     for (int i = 0; i < 6; ++i) s.dofs[i] = xs[(10 + i) * B + b];
 }
+// what the Jacobian blocks of ONE predict depend on: dofs, notch, om_old, acc_old, q_old (19 words); the
+// rest of the register state is left unset and must not be used
+template <typename T>
+__device__ __forceinline__ void load_state_jac(const T* xs, int64_t B, int64_t b, State<T>& s) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        s.notch[i] = xs[(16 + i) * B + b]; s.om_o[i] = xs[(26 + i) * B + b]; s.acc_o[i] = xs[(29 + i) * B + b];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.qo[i] = xs[(32 + i) * B + b];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s.dofs[i] = xs[(10 + i) * B + b];
+}
 template <typename T>
 __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const State<T>& s) {
 #pragma unroll
@@ -449,7 +475,9 @@ __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64
 // ---- lane-per-instance: nominal propagation + residual (blockIdx.y = 0) and Jacobian blocks
 // (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
-template <typename T>
+// ONE: the launch has exactly one predict (the pair step, a single predict) -- its own build, so that the slim
+// Jacobian role below does not share registers and code with the epoch loop
+template <typename T, bool ONE>
 __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
     // Two wavefronts per block work on the same 64 instances: wave 0 propagates the nominal state
     // (and forms the residual), wave 1 forms the Jacobian blocks.  Both read the state before wave 0
@@ -469,8 +497,14 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     const bool live = b_raw < a.B;
     const int64_t b = live ? b_raw : a.B - 1;      // tail lanes recompute the last instance, write nothing
     T* xs = reinterpret_cast<T*>(a.xs);
+    // The Jacobian role of a single-predict launch (the pair step) needs 19 of the 36 state words --
+    // dofs, notch, om_old, acc_old, q_old -- and 9 of the 24 words of a pending error state (ddofs,
+    // dnotch): its blocks are evaluated with the stale buffers (Filter.py:254-255,327: R_WB_old is not
+    // refreshed by an update) and the attitude q only matters as the NEXT predict's q_old.
+    const bool jac_slim = ONE && jac_role;                 // wave-uniform
     State<T> s;
-    load_state(reinterpret_cast<const T*>(a.xs_src), a.B, b, s);
+    if (jac_slim) load_state_jac(reinterpret_cast<const T*>(a.xs_src), a.B, b, s);
+    else load_state(reinterpret_cast<const T*>(a.xs_src), a.B, b, s);
     // Deferred injection.  Whether the workspace holds an update whose error state is still to be
     // injected is DEVICE state -- bit DVI_STATUS_PENDING of the instance's status word, set by the
     // covariance kernel, cleared here (or by the flush kernel) -- so that a captured sequence of steps
@@ -482,8 +516,13 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     int pend_status = 0;
     if (a.pending_hint) {
         pend_status = a.status_ws[b];
+        if (jac_slim) {
 #pragma unroll
-        for (int i = 0; i < 24; ++i) epend[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i];
+            for (int i = 9; i < 18; ++i) epend[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) epend[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i];
+        }
     }
     // (dvi_eskf_step_from reads another handle's flushed state: whatever was due on this one is dropped)
     const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
@@ -504,7 +543,16 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     }
     __syncthreads();                               // every read of the old state (and of the pending
                                                    // error state) precedes this step's writes
-    if (inject_now) inject_error(s, epend);        // the previous update's injection (both roles)
+    if (inject_now) {                              // the previous update's injection (both roles)
+        if (jac_slim) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) s.dofs[i] += epend[9 + i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s.notch[i] += epend[15 + i];
+        } else {
+            inject_error(s, epend);
+        }
+    }
     if (jac_role) {
         // ---- wave 1: Jacobian blocks of every predict of this launch ---------------------------
         const int npiece = prm.jfull ? 43 : 34;    // 16-byte pieces of a record: 85 / 67 words
@@ -520,7 +568,8 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             // the blocks are written straight into this lane's staging row (the struct IS the record),
             // so they do not occupy registers; only this wavefront touches sJ: wave-level ordering
             Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
-            predict_scalar<T, false, true>(s, prm, sig_om, dt, om_n, acc_n, J);
+            if constexpr (ONE) predict_scalar<T, false, true, false>(s, prm, sig_om, dt, om_n, acc_n, J);
+            else predict_scalar<T, false, true>(s, prm, sig_om, dt, om_n, acc_n, J);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -2352,7 +2401,10 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + 9) * sizeof(T);    // + parked measurement
-    hipLaunchKernelGGL(eskf_pre_kernel<T>, dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
+    if (a.n_pred == 1)
+        hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
+    else
+        hipLaunchKernelGGL((eskf_pre_kernel<T, false>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // 2. covariance.  With per-instance noise: the PIN variants (row-resident, or the LDS-image kernel

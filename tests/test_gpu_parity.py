@@ -95,12 +95,12 @@ def _innovation_condition(P, R):
 #     FLOOR + max(C_REF * distance of the literal fp64 oracle from it,  C_COND * cond(S) * eps)
 # -- as accurate as the reference's own arithmetic (times 2), or as the forward-error bound of a backward-stable
 # fp64 solve allows (cond = 2-norm condition of the diagonally equilibrated innovation covariance, eps = 2^-52;
-# the measurement-by-measurement update of the row-resident kernel is an LDL^T solve without pivoting, measured
-# at up to ~8 cond eps), whichever is larger -- and never worse than that; FLOOR is the well-conditioned
-# tolerance of this file's header.  (Measured: at cond 7e4 the kernel is 1e-10 from exact where the reference's
-# LU inverse + Joseph form is 6e-14 from exact: the reference's arithmetic is the more accurate one on
-# ill-conditioned updates, and both are far inside the 1e-9 of the north star.)
-C_REF, C_COND = 2.0, 32.0
+# the measurement-by-measurement update of the row-resident kernel is an LDL^T solve without pivoting),
+# whichever is larger -- and never worse than that; FLOOR is the well-conditioned tolerance of this file's
+# header.  All three start from the same SYMMETRIC covariance (see the test): the exact update of an
+# ill-conditioned instance moves by 1e-8 when the last bit of P's asymmetry is dropped, which would otherwise
+# be charged to whoever stores P packed.
+C_REF, C_COND = 2.0, 4.0
 FLOOR_X, FLOOR_P = 1e-11, 1e-10
 EPS = 2.0 ** -52
 
@@ -165,6 +165,11 @@ def test_forced_single_step_parity(golden, frozen, nframes):
             eP = max(eP, _rel(s["P"], o.P, B))
             assert np.abs(s["om_old"] - o.om_old).max() == 0
             assert np.abs(s["q_old"] - o.x[:, 6:10]).max() < 1e-14
+        # The device stores P symmetric-packed (the lower triangle); the oracle's P = Fx P Fx^T + ... carries a
+        # rounding-level asymmetry (~1e-16 |P|).  Where S is ill-conditioned the EXACT update is sensitive to
+        # that last bit (measured: cond 1.6e6 -> 1e-8 in the state), so all three -- GPU, fp64 oracle, quad
+        # oracle -- are given the same, symmetric input: the lower triangle mirrored.
+        o.P[:] = np.tril(o.P) + np.transpose(np.tril(o.P, -1), (0, 2, 1))
         P_in = o.P.copy()
         f.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old)
         h.x[:], h.P[:] = o.x, o.P                       # the adjudicator starts from the same input

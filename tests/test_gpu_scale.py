@@ -71,6 +71,8 @@ def test_config2_batch1024_perturbed_instances_vs_oracle():
     q_old = o.x[:, 6:10].copy()
     for k in range(8):
         f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
+        # (the device stores the lower triangle of P: every side starts the pair-step from that symmetric input)
+        o.P[:] = np.tril(o.P) + np.transpose(np.tril(o.P, -1), (0, 2, 1))
         forced.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old)
         h.x[:], h.P[:], h.om_old[:], h.acc_old[:], h.Rwb[:] = o.x, o.P, o.om_old, o.acc_old, o.Rwb
         st, _ = forced.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])
