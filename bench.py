@@ -227,13 +227,13 @@ def main():
                         self.f.update(self.wl.pos[i], self.wl.quat[i], self.wl.notch[i])
 
         def capture(self, n):
-            """steps 0..n-1 of a horizon as one HIP graph (n <= H): at ~0.1 ms of kernel time per step the
-            Python/ctypes launch path would otherwise show up in the step time"""
+            """steps 0..n-1 of the step sequence (horizon after horizon) as one HIP graph: at ~0.1 ms of kernel time
+            per step the Python/ctypes launch path would otherwise show up in the step time"""
             if n not in self.graphs:
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
-                    self.eager(0, n)                         # warm-up on the capture stream
+                    self.eager(0, min(n, H))                 # warm-up on the capture stream
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize(dev)
                 g = torch.cuda.CUDAGraph()
@@ -244,13 +244,14 @@ def main():
             return self.graphs[n]
 
         def plan(self, nsteps):
-            """the launches of `nsteps` consecutive steps: whole horizons, then the rest of one, each a graph
-            replay -- every step of the timed region is replayed, none is launched from Python"""
-            use_graph = args.mode == "pair" and not args.no_graph
-            full, rest = divmod(nsteps, H)
-            if not use_graph:
+            """the launches of `nsteps` consecutive steps, each a graph replay -- every step of the timed region is
+            replayed, none is launched from Python: a short region (<= 16 horizons) is ONE graph (one launch from the
+            host), a long one whole blocks of 16 horizons, then the rest"""
+            if not (args.mode == "pair" and not args.no_graph):
                 return [("eager", 0, nsteps)]
-            ops = [("graph", self.capture(H), H)] * full
+            blk = 16 * H
+            full, rest = divmod(nsteps, blk)
+            ops = [("graph", self.capture(blk), blk)] * full
             if rest:
                 ops.append(("graph", self.capture(rest), rest))
             return ops
@@ -401,7 +402,7 @@ def main():
                                  "the first pair-step of a horizon reads the snapshot handle (dvi_eskf_step_from)",
                 "covariance_kernel": "row-resident" if (args.lanes or 1) == 1 else "lds-image, %d lanes/instance" % args.lanes,
                 "hip_graph": graph,
-                "timed_region": "every one of the %d steps is a HIP-graph replay (whole horizons + one graph for the rest)" % K
+                "timed_region": "every one of the %d steps is replayed from a HIP graph (%d graph launch%s)" % (K, len(ops), "" if len(ops) == 1 else "es")
                                 if graph else "steps launched from Python",
                 "untimed_preparation": "%d warm-up steps, graph capture, then %d replayed steps (%.2f s) to reach sustained clocks"
                                        % (W, sustained_steps, args.sustain_seconds),

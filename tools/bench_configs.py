@@ -1,7 +1,9 @@
 """Secondary measurements of SURVEY 8(d) that are not the bench line:
   config #3  predict-only, B = 1 048 576, fp32, 256 consecutive predict launches (P round-trips HBM)
   10:1       v1-literal schedule: epochs of 10 predicts (dt = 0.1) + 1 update in one launch, fp64
-Prints one JSON object per measurement.  usage: bench_configs.py [config3] [epoch10] [--batch3 N]"""
+  config #5  1 kHz IMU / 30 Hz vision, 10 000 IMU steps x B = 8192, fp32 (and fp64), one run_epochs call
+  small      pair steps at B = 8192 (one GPU's share of config #4 at 8 GPUs)
+Prints one JSON object per measurement.  usage: bench_configs.py [config3] [epoch10] [config5] [small] [--batch3 N]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -67,40 +69,56 @@ def epoch10(B=65536, N=10):
             "frac_of_8TBps": B * bytes_per / t / 8e12, "state_restore_every": 4}
 
 
-def config5(B=8192, frames=64):
-    """Config #5 shape: 1 kHz IMU / 30 Hz vision, fp32 -- one launch per camera frame = 33/33/34 predicts
-    (dt = 1e-3) + 1 update, P resident on chip across the predicts.  Synthetic IMU samples (throughput only)."""
-    from dvi_ekf_amd.workloads import monte_carlo_pairs
+def config5(B=8192, reps=3):
+    """BASELINE config #5 as specified (dvi_ekf_amd.workloads.long_horizon): septic smooth-step
+    camera path at 30 Hz, IMU at 1 kHz synthesised on the device, 33/33/34 predicts + 1 update per camera frame,
+    10 000 IMU steps, fp32 -- the whole run enqueued by ONE call of dvi_eskf_run_epochs (300 epochs = 600 launches;
+    P stays on chip across the predicts of an epoch, the IMU stream is shared by the batch).  Resident regime: no
+    HBM-fraction claim."""
+    from dvi_ekf_amd.workloads import long_horizon
     dev = torch.device("cuda:0")
-    wl = monte_carlo_pairs(B, horizon=4, seed=5, device=dev)
-    f = wl.make_filter(dtype=torch.float32)
-    snap = f.clone()
-    from dvi_ekf_amd import noise
-    counts = [33, 33, 34]
-    dts = [torch.full((n,), 1e-3, device=dev, dtype=torch.float32) for n in counts]
-    z = noise.randn(5 << 32, 0, 1, 0, sum(counts), 6, dtype=torch.float32, device=dev)[:, 0]   # one shared IMU stream
-    zs = torch.split(z, counts)
-    oms = [(0.05 * c[:, 0:3]).contiguous() for c in zs]
-    accs = [(1.0 * c[:, 3:6]).contiguous() for c in zs]
-    pos, quat, notch = wl.pos[0].float(), wl.quat[0].float(), wl.notch[0].float()
-    k = [0]
-
-    def frame():
-        if k[0] % 8 == 0:
+    wl = long_horizon(batch=B)
+    out = []
+    for dtype, name in ((torch.float32, "f32"), (torch.float64, "f64")):
+        om, acc = wl.synthesize_imu_on_device(dtype=dtype, device=dev)
+        om, acc = om[1:].contiguous(), acc[1:].contiguous()
+        t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+        dt, pos, quat, notch = t(wl.dt), t(wl.pos), t(wl.quat), t(wl.notch)
+        f = wl.make_filter(dtype=dtype, device=dev)
+        snap = f.clone()
+        times = []
+        for _ in range(reps + 1):
             f.copy_state_from(snap)
-        i = k[0] % 3
-        f.epoch(dts[i], oms[i], accs[i], pos, quat, notch)
-        k[0] += 1
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st, _ = f.run_epochs(wl.n_pred, dt, om, acc, pos, quat, notch)
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e-3)
+        tt = min(times[1:])
+        x = f.x
+        out.append({"config": "#5: 1 kHz IMU / 30 Hz vision, 10 000 IMU steps, smooth_traj camera path, " + name, "batch": B,
+                    "imu_steps": wl.n_steps, "updates": int(len(wl.n_pred)), "seconds_per_run": tt,
+                    "ms_per_frame": tt / len(wl.n_pred) * 1e3, "imu_steps_per_s": B * wl.n_steps / tt, "unit": "instance-steps/s",
+                    "skipped_updates": int((st & 1).sum()), "finite": bool(torch.isfinite(x).all()), "max_abs_x": float(x.abs().max())})
+    return out
 
-    t = _time(frame, frames, warm=6)
-    steps_per_frame = 100.0 / 3
-    return {"config": "#5 shape: 1 kHz IMU / 30 Hz vision, fp32, one launch per frame", "batch": B, "ms_per_frame": t * 1e3,
-            "imu_steps_per_s": B * steps_per_frame / t, "frames_per_s": B / t, "unit": "instance-steps/s",
-            "finite": bool(torch.isfinite(f.x).all())}
+
+def small_batch(B=8192):
+    """BASELINE config #4 as written shards 65 536 instances over 8 GPUs: 8 192 per GPU.  The pair step at that
+    batch (one generation of wavefronts: both kernels are latency-bound)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", str(B), "--no-cpu-baseline", "--no-streaming"],
+                       capture_output=True, text=True)
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    return {"config": "pair steps, fp64, B = %d (one GPU's share of config #4 at 8 GPUs)" % B, "batch": B, "value": d["value"],
+            "unit": d["unit"], "kernel_ms": d["roofline"]["kernel_ms"], "frac_of_8TBps": d["roofline"]["frac"], "valid": d["valid"]}
 
 
 if __name__ == "__main__":
-    what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["config3", "epoch10", "config5"]
+    what = [a for a in sys.argv[1:] if not a.startswith("--")] or ["config3", "epoch10", "config5", "small"]
     B3 = 1048576
     if "--batch3" in sys.argv:
         B3 = int(sys.argv[sys.argv.index("--batch3") + 1])
@@ -109,4 +127,7 @@ if __name__ == "__main__":
     if "epoch10" in what:
         print(json.dumps(epoch10()))
     if "config5" in what:
-        print(json.dumps(config5()))
+        for r in config5():
+            print(json.dumps(r))
+    if "small" in what:
+        print(json.dumps(small_batch()))
