@@ -147,6 +147,28 @@ __device__ __forceinline__ ProbeTrig<T> probe_trig(const T* dofs, T q7) {
     t_sincos(dofs[2] - q7, t.sp, t.cp);
     return t;
 }
+// The sines / cosines of q1, q2, q3 only change when the extrinsics do -- at an injection, or when frozen DOFs
+// are zeroed -- not from one predict of an epoch to the next; phi = q3 - q7 moves with the notch angle.  A lane
+// keeps the values together with the arguments they belong to and re-evaluates what has changed (same
+// arguments, same library calls: bitwise the values of probe_trig).
+template <typename T>
+struct TrigCache {
+    T a1, a2, a3, ph;   // the arguments the cached values belong to (NaN = nothing cached)
+    ProbeTrig<T> t;
+    __device__ __forceinline__ TrigCache() {
+        a1 = a2 = a3 = ph = T(NAN);
+        t.s1 = t.c1 = t.s2 = t.c2 = t.s3 = t.c3 = t.sp = t.cp = T(0);
+    }
+};
+template <typename T>
+__device__ __forceinline__ ProbeTrig<T> probe_trig(const T* dofs, T q7, TrigCache<T>& tc) {
+    if (!(tc.a1 == dofs[0])) { tc.a1 = dofs[0]; t_sincos(dofs[0], tc.t.s1, tc.t.c1); }
+    if (!(tc.a2 == dofs[1])) { tc.a2 = dofs[1]; t_sincos(dofs[1], tc.t.s2, tc.t.c2); }
+    if (!(tc.a3 == dofs[2])) { tc.a3 = dofs[2]; t_sincos(dofs[2], tc.t.s3, tc.t.c3); }
+    const T ph = dofs[2] - q7;
+    if (!(tc.ph == ph)) { tc.ph = ph; t_sincos(ph, tc.t.sp, tc.t.cp); }
+    return tc.t;
+}
 #define E5(s, c, o)   { o[0] = t.s1 * t.s2 * (s) - t.c1 * (c); o[1] = t.s1 * (c) + t.c1 * t.s2 * (s); o[2] = t.c2 * (s); }
 #define E6(s, c, o)   { o[0] = t.s1 * t.s2 * (c) + t.c1 * (s); o[1] = t.c1 * t.s2 * (c) - t.s1 * (s); o[2] = t.c2 * (c); }
 #define E5_1(s, c, o) { o[0] = t.c1 * t.s2 * (s) + t.s1 * (c); o[1] = t.c1 * (c) - t.s1 * t.s2 * (s); o[2] = T(0); }
@@ -202,9 +224,10 @@ struct Jac {
 // ATT = false (Jacobian role of a single-predict launch): the attitude is not advanced either -- the blocks of
 // THIS predict only need the buffers (om_old, acc_old, q_old), dofs and notch; q would only matter as the
 // next predict's q_old.
-template <typename T, bool NOMINAL = true, bool JAC = true, bool ATT = true>
+// CACHE: reuse the trigonometry of the previous predict of the launch where its arguments have not moved
+template <typename T, bool NOMINAL = true, bool JAC = true, bool ATT = true, bool CACHE = true>
 __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& prm, const T* sig_om, T dt,
-                                               const T* om_n, const T* acc_n, Jac<T>& J) {
+                                               const T* om_n, const T* acc_n, Jac<T>& J, TrigCache<T>& tc) {
     static_assert(ATT || (!NOMINAL && JAC), "ATT = false is the Jacobian role only");
     T R[9], Ro[9];
     if (ATT) quat_to_mat(s.q, R);
@@ -221,7 +244,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
         if (NOMINAL) {
             T Rc[9];
             quat_to_mat(s.qc, Rc);
-            const ProbeTrig<T> t = probe_trig(s.dofs, s.notch[0]);
+            const ProbeTrig<T> t = CACHE ? probe_trig(s.dofs, s.notch[0], tc) : probe_trig(s.dofs, s.notch[0]);
             T pB[3], RBC[9], z6[3];
             probe_pose(t, s.dofs, prm.L, prm.st, prm.ct, pB, RBC, z6);
             T a1[3], a2[3], acc_avg[3];
@@ -289,7 +312,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
             for (int j = 0; j < 3; ++j) J.Th[3 * i + j] = OmR[3 * j + i];
     }
     {
-        const ProbeTrig<T> t = probe_trig(s.dofs, s.notch[0]);
+        const ProbeTrig<T> t = CACHE ? probe_trig(s.dofs, s.notch[0], tc) : probe_trig(s.dofs, s.notch[0]);
         const T st = prm.st, ct = prm.ct;
         T z6[3], z6_1[3], z6_2[3], e5[3], e6[3], e5_1[3], e5_2[3], e6_1[3], e6_2[3];
         T a[3], g[3], a_1[3], a_2[3], g_1[3], g_2[3];
@@ -564,12 +587,13 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             for (int i = 0; i < 3; ++i) sig_om[i] = reinterpret_cast<const T*>(a.noise)[b * NOISE_WORDS + 20 + i];
         }
         T dt = dt0, om_n[3] = {om0[0], om0[1], om0[2]}, acc_n[3] = {acc0[0], acc0[1], acc0[2]};
+        TrigCache<T> tc;
         for (int ip = 0; ip < a.n_pred; ++ip) {
             // the blocks are written straight into this lane's staging row (the struct IS the record),
             // so they do not occupy registers; only this wavefront touches sJ: wave-level ordering
             Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
-            if constexpr (ONE) predict_scalar<T, false, true, false>(s, prm, sig_om, dt, om_n, acc_n, J);
-            else predict_scalar<T, false, true>(s, prm, sig_om, dt, om_n, acc_n, J);
+            if constexpr (ONE) predict_scalar<T, false, true, false, false>(s, prm, sig_om, dt, om_n, acc_n, J, tc);
+            else predict_scalar<T, false, true>(s, prm, sig_om, dt, om_n, acc_n, J, tc);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -597,9 +621,10 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     }
     // ---- wave 0: nominal state through every predict, then the residual -------------------------
     T dt = dt0, om_n[3] = {om0[0], om0[1], om0[2]}, acc_n[3] = {acc0[0], acc0[1], acc0[2]};
+    TrigCache<T> tc;
     for (int ip = 0; ip < a.n_pred; ++ip) {
         Jac<T> J;
-        predict_scalar<T, true, false>(s, prm, prm.sig_om, dt, om_n, acc_n, J);
+        predict_scalar<T, true, false, true, !ONE>(s, prm, prm.sig_om, dt, om_n, acc_n, J, tc);
         load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
     }
     if (!live) return;
