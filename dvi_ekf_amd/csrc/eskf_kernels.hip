@@ -2116,6 +2116,15 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 #undef ESKF_PREDICT_ROWS
 }
 
+// state.dofs of every instance (Filter.calculate_dof_metric, Filter.py:452-455; the payload of the final gather)
+template <typename T>
+__global__ __launch_bounds__(256) void calibration_kernel(int64_t B, const T* xs, T* dofs6) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dofs6[b * 6 + i] = xs[(10 + i) * B + b];
+}
+
 // ----------------------------------------------------------------------------------
 // state import / export between the user-facing layout and the device records
 // ----------------------------------------------------------------------------------
@@ -2493,6 +2502,12 @@ hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, 
 
 hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,
                          void* acc3, void* qo4, void* dofs6, hipStream_t stream) {
+    if (dofs6 && !x26 && !P576 && !om3 && !acc3 && !qo4) {      // the calibration estimates only
+        const unsigned nb = (unsigned)((B + 255) / 256);
+        if (dtype == 0) hipLaunchKernelGGL(calibration_kernel<double>, dim3(nb), dim3(256), 0, stream, B, (const double*)xs, (double*)dofs6);
+        else hipLaunchKernelGGL(calibration_kernel<float>, dim3(nb), dim3(256), 0, stream, B, (const float*)xs, (float*)dofs6);
+        return hipGetLastError();
+    }
     const int threads = 256;
     const int64_t work = B * 300;
     const unsigned blocks = (unsigned)((work + threads - 1) / threads > 65535 ? 65535 : (work + threads - 1) / threads);
