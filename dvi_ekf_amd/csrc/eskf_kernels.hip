@@ -495,6 +495,47 @@ __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64
     }
 }
 
+// The 64 Jacobian records a wavefront has staged in LDS (row stride JS words, one row per instance) -> HBM, in
+// 16-byte pieces, as many whole records per store instruction as fit the wavefront (fp64: one record = 34 pieces;
+// fp32: three records of 17 pieces): a wavefront can only have ~64 memory instructions in flight, and at one record
+// per instruction an epoch's predicts queued up behind the acknowledgements of their own stores.  Eight
+// instructions at a time: all their LDS reads are issued, THEN the stores -- the compiler fence in between keeps
+// it from pairing every read with its store and a wait (one LDS round trip per record: 64 x ~120 cycles, which
+// was half of an epoch's pre kernel).
+template <typename T, int JS>
+__device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int lane) {
+    constexpr int PW = 16 / (int)sizeof(T);             // words per piece
+    struct alignas(16) Piece { T w[PW]; };
+    constexpr int NP = (JS + PW - 1) / PW;              // pieces per record
+    constexpr int RPI = 64 / NP;                        // records per store instruction
+    const int rs = lane / NP, pc = lane - rs * NP;
+    if (rs >= RPI) return;
+    const T* src = sJ + pc * PW;
+    const int nw = (JS - pc * PW) > PW ? PW : (JS - pc * PW);   // valid words of this lane's piece
+    auto fetch = [&](int r, Piece& v) {
+#pragma unroll
+        for (int k = 0; k < PW; ++k) v.w[k] = (k < nw) ? src[r * JS + k] : T(0);
+    };
+    T* dst = gJ + pc * PW;
+    int r0 = 0;
+    for (; r0 + 8 * RPI <= nrec; r0 += 8 * RPI) {
+        Piece v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fetch(r0 + u * RPI + rs, v[u]);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) *reinterpret_cast<Piece*>(dst + (int64_t)(r0 + u * RPI + rs) * JW) = v[u];
+    }
+    for (; r0 < nrec; r0 += RPI) {                      // the rest (and the last block of a ragged batch)
+        const int r = r0 + rs;
+        if (r < nrec) {
+            Piece v;
+            fetch(r, v);
+            *reinterpret_cast<Piece*>(dst + (int64_t)r * JW) = v;
+        }
+    }
+}
+
 // ---- lane-per-instance: nominal propagation + residual (blockIdx.y = 0) and Jacobian blocks
 // (blockIdx.y = 1).  The two halves are independent chains of about equal length; giving them to
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
@@ -578,7 +619,6 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     }
     if (jac_role) {
         // ---- wave 1: Jacobian blocks of every predict of this launch ---------------------------
-        const int npiece = prm.jfull ? 43 : 34;    // 16-byte pieces of a record: 85 / 67 words
         // Jacobian evaluation point n = sigma (Filter.py:330-333): per instance when the handle carries
         // per-instance noise
         T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
@@ -599,19 +639,8 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
             const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
-            if (lane < npiece) {
-                using T2 = typename Vec2<T>::type;
-                const bool has_y = 2 * lane + 1 < JS;
-                const T* src = sJ + 2 * lane;
-                T2* dst = reinterpret_cast<T2*>(gJ) + lane;
-#pragma unroll 8
-                for (int r = 0; r < nrec; ++r) {    // (unrolled: the LDS reads of eight records are in flight together)
-                    T2 v;
-                    v.x = src[r * JS];
-                    v.y = has_y ? src[r * JS + 1] : T(0);
-                    dst[(int64_t)r * (JW / 2)] = v;
-                }
-            }
+            if (prm.jfull) store_records<T, J_FULL>(sJ, gJ, nrec, lane);
+            else store_records<T, J_CORE>(sJ, gJ, nrec, lane);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
