@@ -478,9 +478,27 @@ __device__ __forceinline__ void store_state(T* xs, int64_t B, int64_t b, const S
 
 // IMU sample `ip` of instance b; zeros beyond the last one (assigned on every path, so that the
 // registers of the sample before are free as soon as it has been used)
-template <typename T>
+template <typename T, bool SHARED = false>
 __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64_t b, T& dt, T (&om)[3], T (&acc)[3]) {
     if (ip < a.n_pred) {
+        if constexpr (SHARED) {
+            // one IMU stream for the whole batch: the sample is the same for every lane -- fetched with SCALAR
+            // loads (constant address space).  Besides saving vector registers this keeps it off the vector-memory
+            // counter: a vector load issued behind an epoch's record stores is only known to have arrived when
+            // all of those stores have been acknowledged (loads and stores retire in order on one counter), which
+            // exposed the full store latency once per predict.
+            typedef const T __attribute__((address_space(4))) * cptr;
+            cptr cdt = (cptr)(uintptr_t)a.dt;
+            cptr com = (cptr)(uintptr_t)a.om;
+            cptr cacc = (cptr)(uintptr_t)a.acc;
+            dt = cdt[ip];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                om[i] = com[ip * 3 + i];
+                acc[i] = cacc[ip * 3 + i];
+            }
+            return;
+        }
         const int64_t so = a.imu_stride ? ((int64_t)ip * a.B + b) * 3 : (int64_t)ip * 3;
         dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? (int64_t)ip * a.B + b : ip];
 #pragma unroll
@@ -497,11 +515,12 @@ __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64
 
 // The 64 Jacobian records a wavefront has staged in LDS (row stride JS words, one row per instance) -> HBM, in
 // 16-byte pieces, as many whole records per store instruction as fit the wavefront (fp64: one record = 34 pieces;
-// fp32: three records of 17 pieces): a wavefront can only have ~64 memory instructions in flight, and at one record
-// per instruction an epoch's predicts queued up behind the acknowledgements of their own stores.  Eight
-// instructions at a time: all their LDS reads are issued, THEN the stores -- the compiler fence in between keeps
-// it from pairing every read with its store and a wait (one LDS round trip per record: 64 x ~120 cycles, which
-// was half of an epoch's pre kernel).
+// fp32: three records of 17 pieces).  Eight instructions at a time: all their LDS reads are issued, THEN the stores
+// -- the compiler fence in between keeps it from pairing every read with its store and a wait (one LDS round trip
+// per record: 64 x ~120 cycles).  Measured per 33-predict epoch of B = 8192, fp32 (pre kernel): one record per
+// instruction, read-wait-store 144 us; this version 118 us; no stores at all 72 us; the same bytes as 67
+// one-word-per-lane instructions (conflict-free LDS reads) 213 us; as 17 instructions with all 64 lanes busy
+// (pieces of up to four records per instruction) 183 us.
 template <typename T, int JS>
 __device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int lane) {
     constexpr int PW = 16 / (int)sizeof(T);             // words per piece
@@ -541,7 +560,9 @@ __device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int 
 // different waves halves the latency of this kernel (it runs at one or two waves per SIMD).
 // ONE: the launch has exactly one predict (the pair step, a single predict) -- its own build, so that the slim
 // Jacobian role below does not share registers and code with the epoch loop
-template <typename T, bool ONE>
+// SIMU (epoch builds): dt, om, acc are one stream shared by the batch (dt_stride = imu_stride = 0): the samples after
+// the first are fetched with scalar loads, see load_imu_sample
+template <typename T, bool ONE, bool SIMU = false>
 __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
     // Two wavefronts per block work on the same 64 instances: wave 0 propagates the nominal state
     // (and forms the residual), wave 1 forms the Jacobian blocks.  Both read the state before wave 0
@@ -634,17 +655,25 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
             if constexpr (ONE) predict_scalar<T, false, true, false, false>(s, prm, sig_om, dt, om_n, acc_n, J, tc);
             else predict_scalar<T, false, true>(s, prm, sig_om, dt, om_n, acc_n, J, tc);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // (only this wavefront touches the staging rows, and the LDS executes one wavefront's operations in
+            //  order: what is needed is that the COMPILER keeps the staging writes, the reads of the store loop
+            //  and the next predict's writes in program order -- not a wait for outstanding vector-memory
+            //  operations, which a release fence would also imply)
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            asm volatile("" ::: "memory");
             T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
             const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
             if (prm.jfull) store_records<T, J_FULL>(sJ, gJ, nrec, lane);
             else store_records<T, J_CORE>(sJ, gJ, nrec, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            // (only this wavefront touches the staging rows, and the LDS executes one wavefront's operations in
+            //  order: what is needed is that the COMPILER keeps the staging writes, the reads of the store loop
+            //  and the next predict's writes in program order -- not a wait for outstanding vector-memory
+            //  operations, which a release fence would also imply)
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
+            asm volatile("" ::: "memory");
+            load_imu_sample<T, SIMU>(a, ip + 1, b, dt, om_n, acc_n);
         }
         return;
     }
@@ -654,7 +683,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     for (int ip = 0; ip < a.n_pred; ++ip) {
         Jac<T> J;
         predict_scalar<T, true, false, true, !ONE>(s, prm, prm.sig_om, dt, om_n, acc_n, J, tc);
-        load_imu_sample(a, ip + 1, b, dt, om_n, acc_n);
+        load_imu_sample<T, SIMU>(a, ip + 1, b, dt, om_n, acc_n);
     }
     if (!live) return;
     // (output addresses are formed here, from an opaque copy of the instance index: formed in the
@@ -2466,6 +2495,8 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + 9) * sizeof(T);    // + parked measurement
     if (a.n_pred == 1)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
+    else if (!a.imu_stride && !a.dt_stride)
+        hipLaunchKernelGGL((eskf_pre_kernel<T, false, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     else
         hipLaunchKernelGGL((eskf_pre_kernel<T, false>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     hipError_t e = hipGetLastError();
