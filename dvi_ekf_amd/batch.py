@@ -194,9 +194,12 @@ class BatchedESKF:
     def P(self) -> torch.Tensor:
         return self.get_state(("P",))["P"]
 
-    def calibration(self) -> torch.Tensor:
-        """Estimated extrinsic DOFs [B,6] (state.dofs)."""
-        out = torch.empty((self.batch, 6), dtype=self.dtype, device=self.device)
+    def calibration(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Estimated extrinsic DOFs [B,6] (state.dofs); ``out``: a preallocated [B,6] device tensor to fill."""
+        if out is None:
+            out = torch.empty((self.batch, 6), dtype=self.dtype, device=self.device)
+        elif out.shape != (self.batch, 6) or out.dtype != self.dtype or out.device != self.device or not out.is_contiguous():
+            raise ValueError("out must be a contiguous [B,6] tensor of the filter's dtype on its device")
         _capi.check(self.lib.dvi_eskf_get_calibration(self._h, _ptr(out), self._stream()), "dvi_eskf_get_calibration")
         return out
 

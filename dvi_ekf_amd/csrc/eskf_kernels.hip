@@ -2155,16 +2155,21 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     }
     group_sync();
     if (valid) {
+        // (all the reads of the image first, then the stores: read-wait-store per piece is five LDS round trips
+        //  in a row at the very end of the wavefront's life; the last piece's index is clamped instead of
+        //  predicated so that the reads are unconditional)
         T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
+        T2 v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            v[k].x = lds_load1(sB + off[2 * k]);
+            v[k].y = lds_load1(sB + off[2 * k + 1]);
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e2 = lig + k * LPI;
-            if (e2 < 150) {
-                T2 v;
-                v.x = lds_load1(sB + off[2 * k]);
-                v.y = lds_load1(sB + off[2 * k + 1]);
-                gP2[e2] = v;
-            }
+            if (e2 < 150) gP2[e2] = v[k];
         }
     }
 #undef ESKF_LOAD_J
