@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- ESKF predict+update pair-steps/s on MI355X (BASELINE.json metric).
 
-One "step" = one fused predict+update launch over the rank's batch (B = 65 536 filter
+One "step" = one fused predict+update launch pair over the rank's batch (B = 65 536 filter
 instances per GPU, fp64, 26-state / 24 error-state), inputs and state resident in HBM.
 Workload: BASELINE config #2/#4 -- the reference's default run (mandala0_mono, default
 config.yaml) on the 1:1 schedule (dt = 1.0), per-instance perturbed initial extrinsic
 DOFs (unfrozen) and per-instance Gaussian noise on IMU and camera measurements.  The
 reference filter is dynamically unstable on long horizons, so the state is
-restored from a device snapshot every `--horizon` steps; the restore (a device-to-device
-copy of all state) is INSIDE the timed region.
+restored from a device snapshot every `--horizon` steps; the restore is INSIDE the timed
+region (the first step of a horizon reads the snapshot handle).
 
 Single GPU:  python bench.py --steps K --warmup W
 N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                  --master-port P bench.py --gpus N --steps K --warmup W
-Ranks own disjoint instance blocks (weak scaling: 65 536 per GPU); the only collective is
-the final RCCL all-gather of the calibration estimates, inside the timed region.
+Ranks own disjoint instance blocks; the only collective is the final RCCL all-gather of the
+calibration estimates, inside the timed region.  Default: weak scaling, 65 536 instances per GPU
+(what the driver's scaling run expects).  `--strong` is BASELINE config #4 as written: ONE batch of
+`--batch` instances sharded over the ranks (65 536 -> 8 x 8 192); thanks to the counter-based noise
+generator both modes compute, for every global instance, exactly what a single GPU computes for it
+(tests/test_gpu_00_two_rank_rehearsal.py).
+
+Timing: W warm-up steps, graph capture and `--sustain-seconds` of untimed replay (clocks), then a
+barrier + synchronize, EXACTLY K steps replayed from HIP graphs + the calibration read (+ the
+gather), synchronize + barrier; MAX over ranks.  `roofline.frac` is from HIP events around the K
+steps on the launch stream, `roofline.frac_wall` from the host clock (ms_per_step);
+`roofline.streaming` repeats the measurement at a batch that does not fit the Infinity Cache;
+`cpu_baseline` times the C oracle on the host cores on a bounded sample (rank 0, N = 1 only).
 """
 import argparse
 import json
