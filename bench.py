@@ -163,7 +163,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # (DVI_BENCH_FORCE_DIST=1: take the multi-rank code path -- RCCL communicator, barriers, the final all-gather, the
+    #  MAX over ranks -- also with ONE rank; that is how the one-GPU test box exercises the RCCL calls of the N > 1 path)
+    if world > 1 or os.environ.get("DVI_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL prints a version banner on STDOUT when a communicator is created; stdout of this
@@ -372,7 +374,7 @@ def main():
     # the same measurement at a batch whose working set does not fit the 256 MiB Infinity Cache (the headline
     # batch's ~225 MB does): what the step sustains when it has to stream from HBM
     streaming = None
-    if rank == 0 and world == 1 and args.mode == "pair" and not args.no_streaming and not args.no_graph:
+    if rank == 0 and world == 1 and dist is None and args.mode == "pair" and not args.no_streaming and not args.no_graph:
         Bs = args.streaming_batch
         del run.graphs
         big = Run(Bs, 0)
@@ -440,7 +442,8 @@ def main():
                                 if graph else "steps launched from Python",
                 "untimed_preparation": "%d warm-up steps, graph capture, then %d replayed steps (%.2f s) to reach sustained clocks"
                                        % (W, sustained_steps, args.sustain_seconds),
-                "final_collective": "RCCL all_gather of dofs[B,6]" if world > 1 else "none (single GPU)",
+                "final_collective": ("RCCL all_gather of dofs[B,6]" if backend == "nccl" else "gloo all_gather of dofs[B,6] (rehearsal)")
+                                    if dist is not None else "none (single GPU)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -26,12 +26,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(tmp_path, nranks, name):
+def _bench(tmp_path, nranks, name, backend="gloo", force_dist=False):
     out = tmp_path / f"{name}.npy"
     args = ["--gpus", str(nranks), "--steps", "24", "--warmup", "0", "--batch", "2048", "--strong", "--horizon", "8",
             "--no-cpu-baseline", "--dump-dofs", str(out)]
-    env = dict(os.environ, DVI_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if nranks == 1:
+    env = dict(os.environ, DVI_BENCH_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if force_dist:
+        env["DVI_BENCH_FORCE_DIST"] = "1"
+    if nranks == 1 and not force_dist:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
@@ -50,3 +52,14 @@ def test_two_ranks_gather_what_one_process_computes(tmp_path):
     assert dofs1.shape == dofs2.shape == (2048, 6)
     assert np.array_equal(dofs1, dofs2)                     # bit for bit
     assert np.isfinite(dofs1).all() and len(np.unique(dofs1[:, 0])) > 1000
+
+
+def test_rccl_code_path_with_one_rank(tmp_path):
+    """The RCCL calls of the N > 1 path (communicator over the `nccl` backend, device barriers, all-gather of the
+    calibration estimates, MAX over ranks) on the one GPU there is: a one-rank job launched by torch.distributed.run
+    that is forced through the multi-rank code path must produce what the plain single-process run produces."""
+    one, dofs1 = _bench(tmp_path, 1, "plain")
+    rccl, dofs2 = _bench(tmp_path, 1, "rccl", backend="nccl", force_dist=True)
+    assert rccl["valid"] and rccl["n_gpus"] == 1
+    assert "RCCL" in rccl["config"]["final_collective"]
+    assert np.array_equal(dofs1, dofs2)
