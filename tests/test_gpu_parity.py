@@ -570,6 +570,69 @@ def _random_unit_quats(rng, n):
     return q / np.linalg.norm(q, axis=1, keepdims=True)
 
 
+def _random_configuration(rng, B):
+    x0 = np.zeros((B, 26))
+    x0[:, 0:3] = rng.normal(0, 30.0, (B, 3))
+    x0[:, 3:6] = rng.normal(0, 5.0, (B, 3))
+    x0[:, 6:10] = _random_unit_quats(rng, B)
+    x0[:, 10:13] = rng.uniform(-np.pi, np.pi, (B, 3))
+    x0[:, 13:16] = rng.normal(0, 20.0, (B, 3))
+    x0[:, 16] = rng.uniform(-np.pi, np.pi, B)
+    x0[:, 17:19] = rng.normal(0, 0.1, (B, 2))
+    x0[:, 19:22] = rng.normal(0, 30.0, (B, 3))
+    x0[:, 22:26] = _random_unit_quats(rng, B)
+    return x0
+
+
+@pytest.mark.parametrize("frozen,hold,dt_scale,seed", [((0,) * 6, False, 0.1, 11), ((1,) * 6, True, 1e-3, 12)])
+def test_random_configurations_fp32_single_step(frozen, hold, dt_scale, seed):
+    """The fp32 kernels at states nowhere near the reference trajectory (all Markley branches, joint angles and
+    notch over +-pi, per-instance dt, random SPD covariances): one predict and one update from inputs that are
+    exactly representable in fp32, against the fp64 oracle on the same inputs.  Stated tolerance, relative to the
+    instance's magnitude: predict x 2e-6, P 1e-5; update x 2e-4, P 5e-4 (measured 1.1e-7 / 8.4e-7 and 1.1e-5 / 2.7e-5;
+    quaternions compared up to their sign: w ~ 0 may round to either side of the w >= 0 normalisation)."""
+    B = 2048
+    rng = np.random.default_rng(2000 + seed)
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=frozen)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    x0 = f32(_random_configuration(rng, B))
+    A = rng.standard_normal((B, 24, 24)) * 10.0 ** rng.uniform(-1, 0, (B, 24, 1))
+    P0 = f32(A @ A.transpose(0, 2, 1) / 24 + 1e-2 * np.eye(24))
+    P0 = np.tril(P0) + np.transpose(np.tril(P0, -1), (0, 2, 1))
+    om_old, acc_old = f32(rng.normal(0, 0.5, (B, 3))), f32(rng.normal(0, 20.0, (B, 3)))
+    om, acc = f32(rng.normal(0, 0.5, (B, 3))), f32(rng.normal(0, 20.0, (B, 3)))
+    dt = f32(dt_scale * rng.uniform(0.5, 1.5, B))
+    pos = f32(x0[:, 19:22] + rng.normal(0, 1.0, (B, 3)))
+    quat = f32(x0[:, 22:26] + rng.normal(0, 0.05, (B, 4)))
+    notch = f32(x0[:, 16] + rng.normal(0, 0.01, B))
+    Rl = np.diag([1e-2] * 3 + [1e-4] * 3 + [1e-4])           # an innovation covariance fp32 can factorise: see the forced-step test
+    f = _make(cfg, ri, Q, Rl, sa, so, B, hold, x0, dtype=torch.float32)
+    f.set_state(x=x0, P=P0, om_old=om_old, acc_old=acc_old)
+    o = _oracle(cfg, ri, Q, Rl, sa, so, B, hold, x0)
+    o.P[:], o.om_old[:], o.acc_old[:] = P0, om_old, acc_old
+
+    def errs():
+        s = {k_: v.double().cpu().numpy() for k_, v in f.get_state(("x", "P")).items()}
+        x = s["x"].copy()
+        for a, b in ((6, 10), (22, 26)):
+            flip = (x[:, a:b] * o.x[:, a:b]).sum(axis=1) < 0
+            x[flip, a:b] *= -1
+        return _rel(x, o.x, B), (np.abs(s["P"] - o.P).reshape(B, -1).max(axis=1) / np.abs(o.P).reshape(B, -1).max(axis=1)).max()
+
+    f.predict(dt, om, acc)
+    o.predict(dt, om, acc)
+    ex_p, eP_p = errs()
+    # (the update starts from the oracle's prediction on both sides)
+    f.set_state(x=o.x, P=o.P, om_old=o.om_old, acc_old=o.acc_old, q_old=o.x[:, 6:10])
+    st, _ = f.update(pos, quat, notch)
+    o.update(pos, quat, notch)
+    assert ((st.cpu().numpy() & 1) == 0).all() and ((o.status & 1) == 0).all()
+    ex_u, eP_u = errs()
+    print(f"fp32 random configurations frozen={frozen[0]} dt~{dt_scale}: predict x {ex_p:.1e} P {eP_p:.1e}; update x {ex_u:.1e} P {eP_u:.1e}")
+    assert ex_p <= 2e-6 and eP_p <= 1e-5
+    assert ex_u <= 2e-4 and eP_u <= 5e-4
+
+
 @pytest.mark.parametrize("frozen,hold,dt_scale,seed", [((0,) * 6, False, 0.1, 1), ((1, 0, 1, 0, 0, 1), False, 1.0, 2),
                                                        ((1,) * 6, True, 1.0, 3), ((0,) * 6, False, 1e-3, 4)])
 def test_random_configurations_single_step_parity(frozen, hold, dt_scale, seed):
@@ -581,16 +644,7 @@ def test_random_configurations_single_step_parity(frozen, hold, dt_scale, seed):
     B = 2048
     rng = np.random.default_rng(1000 + seed)
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=frozen)
-    x0 = np.zeros((B, 26))
-    x0[:, 0:3] = rng.normal(0, 30.0, (B, 3))
-    x0[:, 3:6] = rng.normal(0, 5.0, (B, 3))
-    x0[:, 6:10] = _random_unit_quats(rng, B)
-    x0[:, 10:13] = rng.uniform(-np.pi, np.pi, (B, 3))
-    x0[:, 13:16] = rng.normal(0, 20.0, (B, 3))
-    x0[:, 16] = rng.uniform(-np.pi, np.pi, B)
-    x0[:, 17:19] = rng.normal(0, 0.1, (B, 2))
-    x0[:, 19:22] = rng.normal(0, 30.0, (B, 3))
-    x0[:, 22:26] = _random_unit_quats(rng, B)
+    x0 = _random_configuration(rng, B)
     A = rng.standard_normal((B, 24, 24)) * 10.0 ** rng.uniform(-2, 0, (B, 24, 1))
     P0 = A @ A.transpose(0, 2, 1) / 24 + 1e-4 * np.eye(24)
     om_old, acc_old = rng.normal(0, 0.5, (B, 3)), rng.normal(0, 20.0, (B, 3))

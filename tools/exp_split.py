@@ -5,7 +5,8 @@ import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from dvi_ekf_amd.workloads import monte_carlo_pairs
 
-B, H, K = 65536, 16, 1024
+import os
+B, H, K = int(os.environ.get("EXP_B", 65536)), 16, 1024
 dev = torch.device("cuda:0")
 
 
