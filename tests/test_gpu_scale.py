@@ -258,3 +258,58 @@ def test_eight_million_instances_address_range():
     assert torch.equal(xbig[B - tail:], xs[:tail])
     assert torch.equal(big.calibration()[B - tail:], small.calibration()[:tail])
     assert bool(torch.isfinite(xbig).all())
+
+
+def test_full_batch_size_independent_properties():
+    """B = 65 536 (the metric's batch), two properties that need no oracle at that size:
+
+    * an update whose measurement noise dwarfs the covariance (R = 1e30 I) is a no-op: the gain is ~1e-30, so the
+      covariance comes back bit for bit and the state to rounding (the quaternions are re-normalised);
+    * what a shard computes does not depend on the batch it is computed in: instances [0, 32 768) and
+      [32 768, 65 536) stepped as two batches equal the same instances stepped as one, bit for bit, after three
+      predict+update pairs (different grid sizes, different wavefront neighbours, same arithmetic)."""
+    from tests.test_gpu_parity import _random_configuration
+    B = 65536
+    dev = torch.device("cuda", 0)
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
+    rng = np.random.default_rng(65536)
+    x0 = _random_configuration(rng, B)
+    for a in (6, 22):                                   # (w >= 0, as every quaternion the filter itself produces)
+        x0[x0[:, a + 3] < 0, a:a + 4] *= -1
+    A = rng.standard_normal((B, 24, 24)).astype(np.float64) * 10.0 ** rng.uniform(-2, 0, (B, 24, 1))
+    P0 = A @ A.transpose(0, 2, 1) / 24 + 1e-4 * np.eye(24)
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    tx, tP = t(x0), t(P0)
+    del A, P0
+    pos, quat = t(x0[:, 19:22] + rng.normal(0, 1.0, (B, 3))), t(x0[:, 22:26] + rng.normal(0, 0.05, (B, 4)))
+    notch = t(x0[:, 16] + rng.normal(0, 0.01, B))
+    om_old, acc_old = t(rng.normal(0, 0.5, (B, 3))), t(rng.normal(0, 20.0, (B, 3)))
+
+    # --- 1. R -> infinity
+    f = _filter(cfg, Q, 1e30 * np.eye(7), sa, so, B, False)
+    f.set_state(x=tx, P=tP, om_old=om_old, acc_old=acc_old)
+    before = f.get_state(("x", "P"))
+    st, _ = f.update(pos, quat, notch)
+    assert int((st & 1).max()) == 0
+    after = f.get_state(("x", "P"))
+    assert torch.equal(before["P"], after["P"])
+    assert float((before["x"] - after["x"]).abs().max()) <= 1e-13
+    del before, after, f
+
+    # --- 2. shard invariance
+    dts = [t(rng.uniform(0.05, 0.2, B)) for _ in range(3)]
+    oms = [t(rng.normal(0, 0.5, (B, 3))) for _ in range(3)]
+    accs = [t(rng.normal(0, 20.0, (B, 3))) for _ in range(3)]
+
+    def run(lo, hi):
+        g = _filter(cfg, Q, R, sa, so, hi - lo, False)
+        g.set_state(x=tx[lo:hi], P=tP[lo:hi], om_old=om_old[lo:hi], acc_old=acc_old[lo:hi])
+        for k in range(3):
+            g.step(dts[k][lo:hi], oms[k][lo:hi], accs[k][lo:hi], pos[lo:hi], quat[lo:hi], notch[lo:hi])
+        return g.get_state(("x", "P"))
+
+    whole = run(0, B)
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        part = run(lo, hi)
+        assert torch.equal(part["x"], whole["x"][lo:hi]) and torch.equal(part["P"], whole["P"][lo:hi])
+    assert bool(torch.isfinite(whole["x"]).all())
