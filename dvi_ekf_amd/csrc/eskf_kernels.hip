@@ -19,6 +19,8 @@
 //   xs [36][B]   structure-of-arrays state: words x26 | om_old3 | acc_old3 | q_old4
 //                (R_WB_old = Rm(q_old), Filter.py:227)
 //   J  [n][B][88], res [B][8], e [B][24], status [B]   workspace between the kernels
+//                (status bit 30 = "this instance's error state still awaits its injection": device state,
+//                 so that captured step sequences replay correctly -- see eskf_pre_kernel)
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
