@@ -13,6 +13,8 @@ region (the first step of a horizon reads the snapshot handle).
 Single GPU:  python bench.py --steps K --warmup W
 N GPUs:      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                  --master-port P bench.py --gpus N --steps K --warmup W
+             or, from a plain shell, `python bench.py --gpus N ...`: without WORLD_SIZE in the environment the
+             script starts that launcher itself as a child process and leaves with its exit code
 Ranks own disjoint instance blocks; the only collective is the final RCCL all-gather of the
 calibration estimates, inside the timed region.  Default: weak scaling, 65 536 instances per GPU
 (what the driver's scaling run expects).  `--strong` is BASELINE config #4 as written: ONE batch of
@@ -151,12 +153,23 @@ def main():
                     help="diagnostic: time only the predict or only the update launch (not the metric)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` from a plain shell: start the N ranks ourselves, one process per GPU, exactly as
+        # the driver's launcher would.  A CHILD process (this one has not touched the GPU and never will): rank 0 of
+        # the child job prints the JSON line on the stdout it inherits; we leave with the job's exit code.
+        import socket
+        import subprocess
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if os.environ.get("DVI_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % max(1, torch.cuda.device_count())   # rehearsal: ranks may share a GPU

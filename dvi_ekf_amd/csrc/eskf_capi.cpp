@@ -73,6 +73,9 @@ bool alloc_buffers(dvi_eskf* h) {
 }
 
 bool stream_is_capturing(hipStream_t s) {
+    // (the legacy NULL stream can never be capturing, and asking about it while ANOTHER stream is in a global-mode
+    //  capture returns hipErrorStreamCaptureImplicit and invalidates that capture)
+    if (s == nullptr) return false;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess) return false;
     return st != hipStreamCaptureStatusNone;
@@ -81,13 +84,18 @@ bool stream_is_capturing(hipStream_t s) {
 // Grow the Jacobian workspace for an n_pred-step epoch.  An allocation and a device-wide
 // synchronisation: neither is allowed while a stream is being captured, so a capturing caller must have
 // sized the workspace beforehand (dvi_eskf_reserve, or one eager epoch of that length) -- DVI_ESKF_ECAPTURE
-// otherwise.  Happens at most once per handle and epoch length.
+// otherwise.  The same answer once ANY step of the handle has been captured: the address of the old workspace
+// is baked into the recorded kernel arguments, and a replay after the old buffer has been freed would write
+// Jacobian records into freed memory.  Happens at most once per handle and epoch length.
 int ensure_jcap(dvi_eskf* h, int n_pred, hipStream_t stream) {
     if (n_pred <= h->jcap) return DVI_ESKF_OK;
-    if (stream_is_capturing(stream)) return DVI_ESKF_ECAPTURE;
+    if (h->captured || stream_is_capturing(stream)) return DVI_ESKF_ECAPTURE;
     void* nj = nullptr;
     if (hipMalloc(&nj, (size_t)n_pred * (size_t)h->B * eskf::JAC_WORDS * elem_size(h->dtype)) != hipSuccess) return DVI_ESKF_ENOMEM;
-    (void)hipDeviceSynchronize();   // earlier launches may still read the old workspace
+    if (hipDeviceSynchronize() != hipSuccess) {   // earlier launches may still read the old workspace
+        (void)hipFree(nj);
+        return DVI_ESKF_EHIP;
+    }
     (void)hipFree(h->d_J);
     h->d_J = nj;
     h->jcap = n_pred;
@@ -291,11 +299,13 @@ int dvi_eskf_set_noise(dvi_eskf* h, const double* Q, const double* R) {
                 if (i != j && R[i * 7 + j] != 0.0) return DVI_ESKF_EINVAL;
         for (int i = 0; i < 7; ++i) if (!std::isfinite(R[i * 7 + i])) return DVI_ESKF_EINVAL;
     }
+    // (a captured step has the per-instance noise buffer among its recorded arguments: it cannot be freed any more)
+    if (h->d_noise && h->captured) return DVI_ESKF_ECAPTURE;
     if (Q) for (int i = 0; i < 13; ++i) h->hp.qd[i] = Q[i * 13 + i];
     if (R) for (int i = 0; i < 7; ++i) h->hp.r[i] = R[i * 7 + i];
     if (h->d_noise) {                 // back to one noise model for the whole batch
         DeviceGuard g(h->device);
-        (void)hipDeviceSynchronize();
+        if (!g.ok || hipDeviceSynchronize() != hipSuccess) return DVI_ESKF_EHIP;
         (void)hipFree(h->d_noise);
         h->d_noise = nullptr;
         h->hp.q_gyro_any = 0;
@@ -491,6 +501,9 @@ int dvi_eskf_reserve(dvi_eskf* h, int n_pred) {
 
 int dvi_eskf_keep_jacobians(dvi_eskf* h, int on) {
     if (!h) return DVI_ESKF_EINVAL;
+    // the record format (with / without the N6 block) is a recorded kernel argument of every captured step: a
+    // replay after a change would leave a record that is half one format, half the other
+    if (h->captured && (on ? 1 : 0) != h->hp.keep_jac) return DVI_ESKF_ECAPTURE;
     h->hp.keep_jac = on ? 1 : 0;
     h->jac_ip = -1;
     return DVI_ESKF_OK;
@@ -584,7 +597,8 @@ const char* dvi_eskf_strerror(int code) {
         case DVI_ESKF_ENODEV: return "no usable HIP device";
         case DVI_ESKF_ENOMEM: return "device memory allocation failed";
         case DVI_ESKF_EHIP: return "HIP runtime call or kernel launch failed";
-        case DVI_ESKF_ECAPTURE: return "the stream is being captured and the call would have to allocate: reserve first";
+        case DVI_ESKF_ECAPTURE: return "a step of this handle is being or has been captured into a HIP graph and the call would have to "
+                                       "replace a buffer the graph refers to: reserve / set_noise / keep_jacobians before the first capture";
         default: return "unknown error";
     }
 }

@@ -26,13 +26,20 @@
  * enqueue kernels and async copies on `stream` and may be recorded with hipStreamBeginCapture and
  * replayed any number of times: whether an update's error injection is still due is kept on the DEVICE
  * (a bit of the per-instance status word), not in the handle, so a replayed sequence continues from
- * whatever the previous replay left behind exactly as the same calls made eagerly would.  Three rules:
+ * whatever the previous replay left behind exactly as the same calls made eagerly would.  Four rules:
  *  (1) an epoch longer than any the handle has run needs a larger workspace -- an allocation, which a
  *      capturing stream cannot do: call dvi_eskf_reserve(h, n_pred) (or run one such epoch) before the
  *      capture, else the call returns DVI_ESKF_ECAPTURE and nothing is recorded;
  *  (2) create, clone, destroy, set_noise*, reserve, imu_synthesize and randn allocate or synchronise: not
  *      capturable;
- *  (3) pointers recorded in a graph (inputs, K_out, status, handles) must stay valid for its replays.
+ *  (3) pointers recorded in a graph (inputs, K_out, status, handles) must stay valid for its replays;
+ *  (4) so must the handle's OWN buffers: once a step of a handle has been captured, every call that would
+ *      replace a buffer or a record format the graph refers to -- a longer epoch or dvi_eskf_reserve beyond
+ *      the workspace size (the Jacobian workspace would be re-allocated), dvi_eskf_set_noise on a handle
+ *      that carries per-instance noise (that buffer would be freed), a change of dvi_eskf_keep_jacobians
+ *      (the record format is a recorded argument) -- returns DVI_ESKF_ECAPTURE and changes nothing, for the
+ *      rest of the handle's life: reserve, choose the noise model and keep_jacobians BEFORE the first capture.
+ *      dvi_eskf_get_jacobians refers to the last predict enqueued through the API, not to what a replay ran last.
  */
 #ifndef DVI_ESKF_H
 #define DVI_ESKF_H
@@ -56,8 +63,9 @@ extern "C" {
 #define DVI_ESKF_ENODEV (-2)    /* no usable HIP device                                         */
 #define DVI_ESKF_ENOMEM (-3)    /* device allocation failed                                     */
 #define DVI_ESKF_EHIP (-4)      /* a HIP runtime call / kernel launch failed                    */
-#define DVI_ESKF_ECAPTURE (-5)  /* the stream is being captured into a HIP graph and the call would
-                                   have to allocate or synchronise (see "HIP graphs" below)      */
+#define DVI_ESKF_ECAPTURE (-5)  /* a step of the handle is being / has been captured into a HIP graph and
+                                   the call would have to allocate, synchronise or replace a buffer
+                                   the graph refers to (see "HIP graphs" above, rules 1 and 4)   */
 
 /* per-instance status word written by update / step */
 #define DVI_ESKF_STATUS_SINGULAR 1  /* innovation covariance not factorisable: state and P left

@@ -26,14 +26,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(tmp_path, nranks, name, backend="gloo", force_dist=False):
+def _bench(tmp_path, nranks, name, backend="gloo", force_dist=False, self_launch=False):
     out = tmp_path / f"{name}.npy"
     args = ["--gpus", str(nranks), "--steps", "24", "--warmup", "0", "--batch", "2048", "--strong", "--horizon", "8",
             "--no-cpu-baseline", "--dump-dofs", str(out)]
     env = dict(os.environ, DVI_BENCH_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if force_dist:
         env["DVI_BENCH_FORCE_DIST"] = "1"
-    if nranks == 1 and not force_dist:
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    if (nranks == 1 and not force_dist) or self_launch:
+        # (self_launch: `python bench.py --gpus N` from a plain shell -- the script starts the launcher itself)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}",
@@ -52,6 +55,15 @@ def test_two_ranks_gather_what_one_process_computes(tmp_path):
     assert dofs1.shape == dofs2.shape == (2048, 6)
     assert np.array_equal(dofs1, dofs2)                     # bit for bit
     assert np.isfinite(dofs1).all() and len(np.unique(dofs1[:, 0])) > 1000
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 --strong ...` with no launcher around it (the shape of the driver's
+    N = 1 command with another N) starts one process per rank itself and prints the one JSON line."""
+    one, dofs1 = _bench(tmp_path, 1, "one_s")
+    two, dofs2 = _bench(tmp_path, 2, "two_s", self_launch=True)
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["valid"]
+    assert np.array_equal(dofs1, dofs2)
 
 
 def test_rccl_code_path_with_one_rank(tmp_path):

@@ -144,3 +144,45 @@ def test_workspace_growth_is_refused_under_capture_and_reserve_fixes_it():
     a, b = f.get_state(), e.get_state()
     for key in a:
         assert torch.equal(a[key], b[key]), key
+
+
+def test_buffers_a_graph_refers_to_are_not_replaced_after_capture():
+    """Rule (4) of the header: once a step of a handle has been captured, a longer eager epoch / reserve (the
+    Jacobian workspace would be re-allocated under the graph), set_noise on a per-instance-noise handle (that
+    buffer would be freed) and a change of keep_jacobians (the record format is a recorded argument) are refused
+    with DVI_ESKF_ECAPTURE -- and the graph still replays correctly afterwards."""
+    B = 12
+    dev = torch.device("cuda", 0)
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False, frozen=(0,) * 6)
+    f = _make(cfg, ri, Q, R, sa, so, B, False)
+    f.set_noise_per_instance(np.tile(np.diag(Q), (B, 1)), np.tile(np.diag(R), (B, 1)))
+    e = f.clone()
+    inp = _inputs(ri, B, 1, dev)[0]
+    st = torch.zeros(B, dtype=torch.int32, device=dev)
+    lib = _capi.lib()
+    import ctypes as C
+    P = lambda x: C.c_void_p(x.data_ptr())
+
+    def step(flt):
+        flt.step(inp["dt"], inp["om"], inp["acc"], inp["pos"], inp["quat"], inp["notch"], status=st)
+
+    g = _capture(lambda: step(f), dev)
+    n = 4
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    dt, om, acc = t(ri.dt[:n]), t(ri.om[:n]), t(ri.acc[:n])
+    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    rc = lib.dvi_eskf_epoch(f._h, n, P(dt), 0, P(om), P(acc), 0, P(inp["pos"]), P(inp["quat"]), P(inp["notch"]), 1, None, P(st), s)
+    assert rc == -5
+    assert lib.dvi_eskf_reserve(f._h, n) == -5
+    dp = C.POINTER(C.c_double)
+    q = np.ascontiguousarray(Q, dtype=np.float64)
+    assert lib.dvi_eskf_set_noise(f._h, q.ctypes.data_as(dp), None) == -5
+    assert lib.dvi_eskf_keep_jacobians(f._h, 1) == -5
+    assert lib.dvi_eskf_keep_jacobians(f._h, 0) == 0          # (no change: fine)
+    assert b"captured" in lib.dvi_eskf_strerror(-5)
+    g.replay()
+    step(e)
+    torch.cuda.synchronize(dev)
+    a, b = f.get_state(), e.get_state()
+    for key in a:
+        assert torch.equal(a[key], b[key]), key
