@@ -12,6 +12,10 @@
 #include "../../include/dvi_eskf.h"
 #include "eskf_device.h"
 
+#ifdef ESKF_X_STAMPS
+namespace eskf { hipError_t x_read_stamps(unsigned long long* out); }
+#endif
+
 struct dvi_eskf {
     int64_t B;
     int dtype;
@@ -589,6 +593,10 @@ int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, 
                                       (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
+
+#ifdef ESKF_X_STAMPS
+int dvi_eskf_x_stamps(unsigned long long* out) { return eskf::x_read_stamps(out) == hipSuccess ? 0 : -4; }
+#endif
 
 const char* dvi_eskf_strerror(int code) {
     switch (code) {

@@ -25,6 +25,7 @@
 
 #include <type_traits>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "eskf_device.h"
 
@@ -33,9 +34,17 @@ namespace eskf {
 // ----------------------------------------------------------------------------------
 // small math on register arrays
 // ----------------------------------------------------------------------------------
+#ifdef ESKF_X_CHEAP_SINCOS   // timing experiment only (wrong numbers): what the trigonometry costs
+__device__ __forceinline__ void t_sincos(double a, double& s, double& c) { s = a; c = fma(-0.5 * a, a, 1.0); }
+#else
 __device__ __forceinline__ void t_sincos(double a, double& s, double& c) { sincos(a, &s, &c); }
+#endif
 __device__ __forceinline__ void t_sincos(float a, float& s, float& c) { sincosf(a, &s, &c); }
+#ifdef ESKF_X_CHEAP_SQRT     // timing experiment only: raw v_sqrt_f64 (~1e-8 relative)
+__device__ __forceinline__ double t_sqrt(double a) { return __builtin_amdgcn_sqrt(a); }
+#else
 __device__ __forceinline__ double t_sqrt(double a) { return sqrt(a); }
+#endif
 __device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
 __device__ __forceinline__ double t_asin(double a) { return asin(a); }
 __device__ __forceinline__ float t_asin(float a) { return asinf(a); }
@@ -524,7 +533,7 @@ __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64
 // one-word-per-lane instructions (conflict-free LDS reads) 213 us; as 17 instructions with all 64 lanes busy
 // (pieces of up to four records per instruction) 183 us.
 template <typename T, int JS>
-__device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int lane) {
+__device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int lane, int first = 0) {
     constexpr int PW = 16 / (int)sizeof(T);             // words per piece
     struct alignas(16) Piece { T w[PW]; };
     constexpr int NP = (JS + PW - 1) / PW;              // pieces per record
@@ -538,7 +547,7 @@ __device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int 
         for (int k = 0; k < PW; ++k) v.w[k] = (k < nw) ? src[r * JS + k] : T(0);
     };
     T* dst = gJ + pc * PW;
-    int r0 = 0;
+    int r0 = first;     // (records [first, nrec): several wavefronts may share the rows of a block)
     for (; r0 + 8 * RPI <= nrec; r0 += 8 * RPI) {
         Piece v[8];
 #pragma unroll
@@ -724,6 +733,455 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     }
     if (a.n_pred > 0 || a.pending_hint || a.xs_src != a.xs) store_state(xs, a.B, bo, s);   // (unchanged in place otherwise)
     if (was_pending) a.status_ws[bo] = pend_status & ~DVI_STATUS_PENDING;                  // the injection is done (or dropped)
+}
+
+// ----------------------------------------------------------------------------------
+// eskf_pre4_kernel: the pre kernel of a launch with exactly ONE predict (the pair step, a single predict),
+// re-cut into four short chains.  Four wavefronts share 64 instances (lane = instance); what one chain needs from
+// another crosses LDS at two block barriers:
+//
+//   phase A (before barrier 1)                                        phase B (after it)
+//   W0  p, v, q: injection, R, R+, acc_avg, p+, v+, q+ (Markley)      p_CB from the trigonometry -> pc+, r_p
+//   W1  qc: injection, Rm(qc); measurement quaternion turned by the   R_BC, z6 -> C_om -> qc+ (Markley) -> r_theta,
+//       notch angle; notch states                                     r_notch
+//   W2  dofs: injection; sincos(q1), sincos(q2); R_o, blocks A,       p_CB, J_p at dofs+ -> blocks Bm, Cm
+//       Theta, dt
+//   W3  sincos(q3), sincos(phi), sincos(phi+)                         R_BC+ and its derivatives -> blocks Dm, Em
+//
+// then barrier 2 and all four wavefronts move the 64 staged records to HBM.  The eight sincos evaluations of a
+// pair step (two injections, four joint angles, phi after the predict, the notch measurement) -- a third of the
+// old kernel's dependent chain -- are spread two per wavefront, and every chain fits 128 VGPRs (four blocks per CU,
+// sixteen wavefronts; the two-role kernel above needs 217 and runs at two per SIMD).  Same helper functions, same
+// operation order per output as predict_scalar: the results are the same bits.
+// The trigonometry of the Jacobian blocks is evaluated at the post-predict dofs / notch (Filter.py:220-221,325-326):
+// q1..q3 only differ from the nominal ones where a frozen DOF is zeroed (then sin = 0, cos = 1 exactly),
+// phi+ = q3+ - (theta + dt theta') gets its own evaluation unless it equals phi.
+// ----------------------------------------------------------------------------------
+#ifdef ESKF_X_STAMPS        // diagnostic build only: wall-clock stamps (100 MHz) of every block of the last pre4 launch
+__device__ unsigned long long g_x_stamps[8 * 4096];
+#define ESKF_STAMP(K) { if (lane == 0 && blockIdx.x < 4096) g_x_stamps[(K) * 4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); }
+hipError_t x_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x_stamps), sizeof(g_x_stamps)); }
+#else
+#define ESKF_STAMP(K)
+#endif
+constexpr int PRE4_TRIG = 10;       // s1 c1 s2 c2 | s3 c3 sp cp sp+ cp+
+constexpr int PRE4_XW = PRE4_TRIG + 3;   // + r_p (3): 64 x (67 + 13) words = 40 960 B, four blocks per CU exactly
+template <typename T>
+__device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0, int n, T* dst) {
+#pragma unroll
+#ifdef ESKF_X_COALESCED_E   // timing experiment only (wrong words): the pending error state read lane-contiguously
+    for (int i = 0; i < n; ++i) dst[i] = reinterpret_cast<const T*>(a.e)[(b & ~(int64_t)63) * 24 + (i0 + i) * 64 + (b & 63)];
+#else
+    for (int i = 0; i < n; ++i) dst[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i0 + i];
+#endif
+}
+template <typename T>
+__global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams<T> prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sJ = reinterpret_cast<T*>(smem_raw);
+    const int JS = prm.jfull ? J_FULL : J_CORE;
+    T* sX = sJ + 64 * JS;                              // [PRE4_XW][64] exchange words, lane-contiguous
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;                 // wave-uniform
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int64_t b_raw = b0 + lane;
+    const bool live = b_raw < a.B;
+    const int64_t b = live ? b_raw : a.B - 1;          // tail lanes recompute the last instance, write nothing
+    const T* xi = reinterpret_cast<const T*>(a.xs_src);
+    T* xo = reinterpret_cast<T*>(a.xs);
+    const int64_t B = a.B;
+#ifdef ESKF_X_STAGGER       // experiment: every other block starts ESKF_X_STAGGER x 0.5 us late
+    if (blockIdx.x & 1) {
+        for (int k = 0; k < ESKF_X_STAGGER; ++k) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
+    auto X = [&](int w) { return xi[(int64_t)w * B + b]; };
+    // deferred injection: device state, see eskf_pre_kernel
+    int pend_status = 0;
+    if (a.pending_hint) pend_status = a.status_ws[b];
+    const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
+    const bool inject_now = was_pending && !a.drop_pending && !(pend_status & DVI_STATUS_SINGULAR);
+    const T dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? b : 0];
+    Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);    // this lane's staging row (W2, W3)
+    if (role == 0) ESKF_STAMP(0)
+
+    if (role == 0) {
+        // ---- W0: position, velocity, attitude --------------------------------------------------------
+        T p[3], v[3], q[4], pc[3], om_o[3], acc_o[3], q456[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            p[i] = X(0 + i); v[i] = X(3 + i); pc[i] = X(19 + i); om_o[i] = X(26 + i); acc_o[i] = X(29 + i);
+            q456[i] = X(13 + i);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = X(6 + i);
+        T e9[9], e1215[3], e1821[3];
+        if (a.pending_hint) { load_epend(a, b, 0, 9, e9); load_epend(a, b, 12, 3, e1215); load_epend(a, b, 18, 3, e1821); }
+        const int64_t so = a.imu_stride ? b * 3 : 0;
+        T om_n[3], acc_n[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { om_n[i] = reinterpret_cast<const T*>(a.om)[so + i]; acc_n[i] = reinterpret_cast<const T*>(a.acc)[so + i]; }
+        T gpos[3] = {T(0), T(0), T(0)};
+        if (a.do_update) {
+            const T* gp = reinterpret_cast<const T*>(a.pos) + (a.meas_stride ? b : 0) * 3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) gpos[i] = gp[i];
+        }
+#ifdef ESKF_X_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ESKF_STAMP(1)
+        if (inject_now) {                               // state.py:46-60,105-129
+            T th[3] = {e9[6], e9[7], e9[8]}, dq[4], qn[4];
+            quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
+            quat_mul(q, dq, qn);
+            quat_nrm(qn);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { p[i] += e9[i]; v[i] += e9[3 + i]; pc[i] += e1821[i]; q456[i] += e1215[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = qn[i];
+        }
+        T R[9], om_avg[3], w[3], RS[9], Rn[9], a1[3], a2[3], acc_avg[3], qn[4];
+        quat_to_mat(q, R);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { om_avg[i] = (om_o[i] + om_n[i]) * T(0.5); w[i] = dt * om_avg[i]; }
+        mat3_skew(R, w, RS);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rn[i] = R[i] + RS[i];                           // equations.py:46
+        mat3_vec(R, acc_o, a1);
+        mat3_vec(Rn, acc_n, a2);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);          // equations.py:47
+        mat_to_quat(Rn, qn);                                                        // state.py:67
+        ESKF_STAMP(2)
+        __syncthreads();                                // barrier 1: old state read by everyone, trigonometry published
+        ESKF_STAMP(3)
+        ProbeTrig<T> t;
+        t.s1 = sX[0 * 64 + lane]; t.c1 = sX[1 * 64 + lane]; t.s2 = sX[2 * 64 + lane]; t.c2 = sX[3 * 64 + lane];
+        t.s3 = sX[4 * 64 + lane]; t.c3 = sX[5 * 64 + lane];
+        T pB[3];
+        {
+            T z6[3], e5[3], e6[3];
+            z6[0] = -t.s1 * t.c2; z6[1] = -t.c1 * t.c2; z6[2] = t.s2;
+            E5(t.s3, t.c3, e5); E6(t.s3, t.c3, e6);
+            const T lq = prm.L - q456[0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pB[i] = lq * z6[i] + q456[1] * e5[i] + q456[2] * e6[i];
+        }
+        T cr[3], Rcr[3];
+        cross3(om_avg, pB, cr);                                                     // BB_v_CB == 0
+        mat3_vec(R, cr, Rcr);
+        T rp[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const T vi = v[i];
+            p[i] = p[i] + dt * vi + (dt * dt * T(0.5)) * acc_avg[i];                // equations.py:76
+            v[i] = vi + dt * acc_avg[i];                                            // equations.py:77
+            pc[i] = pc[i] + dt * vi + dt * Rcr[i];                                  // equations.py:83-85
+            rp[i] = gpos[i] - pc[i];                                                // Filter.py:369
+        }
+        if (a.do_update) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sX[(PRE4_TRIG + i) * 64 + lane] = rp[i];
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                xo[(0 + i) * B + b] = p[i]; xo[(3 + i) * B + b] = v[i]; xo[(19 + i) * B + b] = pc[i];
+                xo[(26 + i) * B + b] = om_n[i]; xo[(29 + i) * B + b] = acc_n[i];    // Filter.py:225-227
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xo[(6 + i) * B + b] = qn[i]; xo[(32 + i) * B + b] = qn[i]; }
+        }
+    } else if (role == 1) {
+        // ---- W1: camera attitude, notch states, rotation and notch residuals -------------------------------
+        T qc[4], notch[3], om_o[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { notch[i] = X(16 + i); om_o[i] = X(26 + i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qc[i] = X(22 + i);
+        T e69[3], e1518[3], e2124[3];
+        if (a.pending_hint) { load_epend(a, b, 6, 3, e69); load_epend(a, b, 15, 3, e1518); load_epend(a, b, 21, 3, e2124); }
+        T qraw[4] = {T(0), T(0), T(0), T(1)}, ang_notch = T(0);
+        if (a.do_update) {
+            const int64_t mo = a.meas_stride ? b : 0;
+            const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qraw[i] = gq[i];
+            ang_notch = reinterpret_cast<const T*>(a.notch)[mo];
+        }
+        if (inject_now) {
+            T dqc[4], qcn[4];
+            quat_about_axis(t_sqrt(e2124[0] * e2124[0] + e2124[1] * e2124[1] + e2124[2] * e2124[2]), e69, dqc);   // sic (state.py:124)
+            quat_mul(qc, dqc, qcn);
+            quat_nrm(qcn);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qc[i] = qcn[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) notch[i] += e1518[i];
+        }
+        T Rc[9], qm[4];
+        quat_to_mat(qc, Rc);
+        if (a.do_update) {                                                          // Filter.py:364-365
+            T nq[4] = {T(0), T(0), T(0), T(1)};
+            t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
+            quat_mul(nq, qraw, qm);
+            quat_nrm(qm);
+            qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
+        }
+        __syncthreads();                                // barrier 1
+        ProbeTrig<T> t;
+        t.s1 = sX[0 * 64 + lane]; t.c1 = sX[1 * 64 + lane]; t.s2 = sX[2 * 64 + lane]; t.c2 = sX[3 * 64 + lane];
+        t.sp = sX[6 * 64 + lane]; t.cp = sX[7 * 64 + lane];
+        T RBC[9], z6[3];
+        {
+            T aa[3], g[3];
+            z6[0] = -t.s1 * t.c2; z6[1] = -t.c1 * t.c2; z6[2] = t.s2;
+            E5(t.sp, t.cp, aa); E6(t.sp, t.cp, g);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                RBC[3 * i + 0] = -aa[i];
+                RBC[3 * i + 1] = prm.ct * g[i] + prm.st * z6[i];
+                RBC[3 * i + 2] = -prm.st * g[i] + prm.ct * z6[i];
+            }
+        }
+        T u[3], C_om[3], wc[3], RcS[9], Rcn[9], qcn[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = om_o[i] + z6[i] * notch[1];
+        mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wc[i] = dt * C_om[i];
+        mat3_skew(Rc, wc, RcS);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rcn[i] = Rc[i] + RcS[i];                        // equations.py:86
+        mat_to_quat(Rcn, qcn);                                                      // state.py:72
+        notch[0] += dt * notch[1];                                                  // equations.py:80-82
+        notch[1] += dt * notch[2];
+        T r[4] = {T(0), T(0), T(0), T(0)}, flag = T(0);
+        if (a.do_update) {                                                          // Filter.py:370-372
+            T qe[4];
+            quat_mul(qm, qcn, qe);
+            quat_nrm(qe);
+            T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
+            if (nv > T(1)) { nv = T(1); flag = T(1); }
+            const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+            const T f = (nv == T(0)) ? T(0) : ang / nv;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) r[i] = f * qe[i];
+            r[3] = ang_notch - notch[0];
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xo[(16 + i) * B + b] = notch[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xo[(22 + i) * B + b] = qcn[i];
+        }
+        __syncthreads();                                // barrier 2 (r_p is there)
+        if (live) {
+            if (a.do_update) {
+                const T r0 = sX[(PRE4_TRIG + 0) * 64 + lane], r1 = sX[(PRE4_TRIG + 1) * 64 + lane], r2 = sX[(PRE4_TRIG + 2) * 64 + lane];
+                // a NaN / inf measurement or state propagates exactly as it does in the reference (NumPy
+                // arithmetic, no check); the instance is flagged, its neighbours are not affected
+                if (!t_finite(r0 + r1 + r2 + r[0] + r[1] + r[2] + r[3])) flag = T(1);
+                T* gr = reinterpret_cast<T*>(a.res) + b * 8;
+                gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = r[0]; gr[4] = r[1]; gr[5] = r[2]; gr[6] = r[3];
+                gr[7] = flag;                                     // asin argument was clamped, or non-finite residual
+            }
+            if (was_pending) a.status_ws[b] = pend_status & ~DVI_STATUS_PENDING;      // the injection is done (or dropped)
+        }
+    } else {
+        // ---- W2 / W3: Jacobian blocks (Filter.py:249-342), evaluated at the post-predict dofs / notch with the
+        // pre-predict buffers om_old, acc_old, R_WB_old
+        T dofs[6], notch[3], om_o[3], e918[9];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dofs[i] = X(10 + i);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { notch[i] = X(16 + i); om_o[i] = X(26 + i); }
+        if (a.pending_hint) load_epend(a, b, 9, 9, e918);
+        T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
+        if (a.noise) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sig_om[i] = reinterpret_cast<const T*>(a.noise)[b * NOISE_WORDS + 20 + i];
+        }
+        T acc_o[3], qo[4];
+        if (role == 2) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc_o[i] = X(29 + i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qo[i] = X(32 + i);
+        }
+        if (inject_now) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dofs[i] += e918[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) notch[i] += e918[6 + i];
+        }
+        // what the nominal propagation evaluates the probe at (pre-predict) ...
+        const T q1n = dofs[0], q2n = dofs[1], q3n = dofs[2];
+        const T phi = q3n - notch[0];
+        // ... and what the Jacobians are evaluated at (post-predict): frozen DOFs zeroed, notch advanced
+        bool zeroed[3] = {false, false, false};
+        if (!prm.hold_frozen) {                                                     // Filter.py:243-245
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if ((prm.frozen_mask >> i) & 1) { dofs[i] = T(0); if (i < 3) zeroed[i] = true; }
+        }
+        notch[0] += dt * notch[1];                                                  // equations.py:80-82
+        notch[1] += dt * notch[2];
+        const T phi_n = dofs[2] - notch[0];
+        T Ro[9];
+        if (role == 2) {
+            T s1, c1, s2, c2;
+            t_sincos(q1n, s1, c1);
+            t_sincos(q2n, s2, c2);
+            sX[0 * 64 + lane] = s1; sX[1 * 64 + lane] = c1; sX[2 * 64 + lane] = s2; sX[3 * 64 + lane] = c2;
+            quat_to_mat(qo, Ro);
+            J.dt = dt;
+            T w[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) w[i] = -dt * acc_o[i];
+            mat3_skew(Ro, w, J.A);                                                  // -dt R_o [a_o]x
+            T Om[4] = {T(0.5) * dt * om_o[0], T(0.5) * dt * om_o[1], T(0.5) * dt * om_o[2], T(1)};
+            T OmR[9];
+            quat_to_mat(Om, OmR);                                                   // Filter.py:132-134
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) J.Th[3 * i + j] = OmR[3 * j + i];
+        } else {
+            T s3, c3, sp, cp, spn, cpn;
+            t_sincos(q3n, s3, c3);
+            t_sincos(phi, sp, cp);
+            if (phi_n == phi) { spn = sp; cpn = cp; }
+            else t_sincos(phi_n, spn, cpn);
+            sX[4 * 64 + lane] = s3; sX[5 * 64 + lane] = c3; sX[6 * 64 + lane] = sp; sX[7 * 64 + lane] = cp;
+            sX[8 * 64 + lane] = spn; sX[9 * 64 + lane] = cpn;
+        }
+        __syncthreads();                                // barrier 1
+        ProbeTrig<T> t;                                 // at the post-predict dofs / notch
+        t.s1 = zeroed[0] ? T(0) : sX[0 * 64 + lane]; t.c1 = zeroed[0] ? T(1) : sX[1 * 64 + lane];
+        t.s2 = zeroed[1] ? T(0) : sX[2 * 64 + lane]; t.c2 = zeroed[1] ? T(1) : sX[3 * 64 + lane];
+        t.s3 = zeroed[2] ? T(0) : sX[4 * 64 + lane]; t.c3 = zeroed[2] ? T(1) : sX[5 * 64 + lane];
+        t.sp = sX[8 * 64 + lane]; t.cp = sX[9 * 64 + lane];
+        const T thd = notch[1];
+        T om_t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) om_t[i] = om_o[i] - sig_om[i];
+        if (role == 2) {
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xo[(10 + i) * B + b] = dofs[i];
+            }
+            T z6[3], z6_1[3], z6_2[3], e5[3], e6[3], e5_1[3], e5_2[3], e6_1[3], e6_2[3];
+            z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
+            z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
+            z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
+            E5(t.s3, t.c3, e5);     E6(t.s3, t.c3, e6);
+            E5_1(t.s3, t.c3, e5_1); E6_1(t.s3, t.c3, e6_1);
+            E5_2(t.s3, t.c3, e5_2); E6_2(t.s3, t.c3, e6_2);
+            const T lq = prm.L - dofs[3], q5 = dofs[4], q6 = dofs[5];
+            T p[3], Jp[18];   // Jp[3][6]: d p_CB / d q1..q6 (the q7 column is identically zero)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                p[i] = lq * z6[i] + q5 * e5[i] + q6 * e6[i];
+                Jp[6 * i + 0] = lq * z6_1[i] + q5 * e5_1[i] + q6 * e6_1[i];
+                Jp[6 * i + 1] = lq * z6_2[i] + q5 * e5_2[i] + q6 * e6_2[i];
+                Jp[6 * i + 2] = q5 * e6[i] - q6 * e5[i];
+                Jp[6 * i + 3] = -z6[i];
+                Jp[6 * i + 4] = e5[i];
+                Jp[6 * i + 5] = e6[i];
+            }
+            // noise symbols are evaluated at their std-devs (Filter.py:330-333); "true" v_CB := p_CB (Probe.py:458)
+            T wv[3], cr[3];
+            cross3(om_t, p, cr);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wv[i] = -dt * (p[i] + cr[i]);
+            mat3_skew(Ro, wv, J.Bm);                                                // -dt R_o [p + om_t x p]x
+            T RoS[9], M[9];                                                         // M = dt R_o (I + [om_t]x);  Cm = M Jp
+            mat3_skew(Ro, om_t, RoS);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) M[i] = dt * (Ro[i] + RoS[i]);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    J.Cm[6 * r + c] = M[3 * r] * Jp[c] + M[3 * r + 1] * Jp[6 + c] + M[3 * r + 2] * Jp[12 + c];
+            if (prm.jfull) {    // noise Jacobian, camera position rows: dt R_o [p]x
+                T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
+                mat3_skew(Ro, dp, J.N6);
+            }
+        } else {
+            const T st = prm.st, ct = prm.ct;
+            T z6[3], z6_1[3], z6_2[3], aa[3], g[3], a_1[3], a_2[3], g_1[3], g_2[3];
+            z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
+            z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
+            z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
+            E5(t.sp, t.cp, aa);     E6(t.sp, t.cp, g);
+            E5_1(t.sp, t.cp, a_1);  E6_1(t.sp, t.cp, g_1);
+            E5_2(t.sp, t.cp, a_2);  E6_2(t.sp, t.cp, g_2);
+            T RBC[9], u_t[3], u_o[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                RBC[3 * i + 0] = -aa[i];
+                RBC[3 * i + 1] = ct * g[i] + st * z6[i];
+                RBC[3 * i + 2] = -st * g[i] + ct * z6[i];
+                u_t[i] = om_t[i] + z6[i] * thd;
+                u_o[i] = om_o[i] + z6[i] * thd;
+            }
+            // delta-theta_C rows: d/dq_i [ R_BC^T (om_t + z6 thd) ] with only R_BC and z6 depending on q
+            // columns of dR_BC/dq_i are (-da, ct dg + st dz, -st dg + ct dz)
+            auto dcol = [&](const T* da, const T* dg, const T* dz, const T* dzr, int col) {
+                T d0 = T(0), d1 = T(0), d2 = T(0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    d0 += -da[k] * u_t[k];
+                    d1 += (ct * dg[k] + st * dz[k]) * u_t[k];
+                    d2 += (-st * dg[k] + ct * dz[k]) * u_t[k];
+                }
+                T rz[3];
+                mat3T_vec(RBC, dzr, rz);
+                J.Dm[0 * 4 + col] = dt * (d0 + rz[0] * thd);
+                J.Dm[1 * 4 + col] = dt * (d1 + rz[1] * thd);
+                J.Dm[2 * 4 + col] = dt * (d2 + rz[2] * thd);
+            };
+            const T zero3[3] = {T(0), T(0), T(0)};
+            T ma[3] = {-aa[0], -aa[1], -aa[2]}, mg[3] = {-g[0], -g[1], -g[2]};
+            dcol(a_1, g_1, z6_1, z6_1, 0);      // q1
+            dcol(a_2, g_2, z6_2, z6_2, 1);      // q2
+            dcol(g, ma, zero3, zero3, 2);       // q3:  da/dphi = g, dg/dphi = -a
+            dcol(mg, aa, zero3, zero3, 3);      // q7:  phi = q3 - q7
+            T ac[3], bc[3], hs[3];
+            mat3T_vec(RBC, u_t, ac);
+            mat3T_vec(RBC, u_o, bc);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) hs[i] = T(0.5) * dt * (ac[i] + bc[i]);
+            // Em = I - [hs]x
+            J.Em[0] = T(1);   J.Em[1] = hs[2];  J.Em[2] = -hs[1];
+            J.Em[3] = -hs[2]; J.Em[4] = T(1);   J.Em[5] = hs[0];
+            J.Em[6] = hs[1];  J.Em[7] = -hs[0]; J.Em[8] = T(1);
+            if (prm.jfull) {    // noise Jacobian, camera attitude rows: -dt R_BC^T
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
+            }
+        }
+    }
+    if (role == 0) ESKF_STAMP(4)
+    if (role != 1) __syncthreads();                     // barrier 2: the 64 staged records are complete
+    if (role == 0) ESKF_STAMP(5)
+    {
+        T* gJ = reinterpret_cast<T*>(a.J) + b0 * JW;
+        const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
+        const int first = role * 16, last = (first + 16 < nrec) ? first + 16 : nrec;
+        if (prm.jfull) store_records<T, J_FULL>(sJ, gJ, last, lane, first);
+        else store_records<T, J_CORE>(sJ, gJ, last, lane, first);
+    }
+    if (role == 0) ESKF_STAMP(6)
+#ifdef ESKF_X_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (role == 0) ESKF_STAMP(7)
+#endif
 }
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
@@ -2495,12 +2953,19 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     return hipGetLastError();
 }
 
+// diagnostic switch (environment DVI_ESKF_PRE_LEGACY=1, read once): single-predict launches through the two-role
+// pre kernel instead of eskf_pre4_kernel -- the A/B of the two and the bitwise test of one against the other
+static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEGACY"); return e && e[0] == '1'; }();
+
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + 9) * sizeof(T);    // + parked measurement
-    if (a.n_pred == 1)
+    if (a.n_pred == 1 && !g_pre_legacy) {
+        const size_t stage4 = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + PRE4_XW) * sizeof(T);
+        hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
+    } else if (a.n_pred == 1)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     else if (!a.imu_stride && !a.dt_stride)
         hipLaunchKernelGGL((eskf_pre_kernel<T, false, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
