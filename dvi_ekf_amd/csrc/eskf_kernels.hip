@@ -762,7 +762,7 @@ __device__ unsigned long long g_x_stamps[8 * 4096];
 #define ESKF_STAMP(K) { if (lane == 0 && blockIdx.x < 4096) g_x_stamps[(K) * 4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); }
 hipError_t x_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x_stamps), sizeof(g_x_stamps)); }
 #else
-#define ESKF_STAMP(K)
+#define ESKF_STAMP(K) {}
 #endif
 constexpr int PRE4_TRIG = 10;       // s1 c1 s2 c2 | s3 c3 sp cp sp+ cp+
 constexpr int PRE4_XW = PRE4_TRIG + 3;   // + r_p (3): 64 x (67 + 13) words = 40 960 B, four blocks per CU exactly
