@@ -27,7 +27,6 @@ struct dvi_eskf {
     // workspace of the step pipeline (pre -> cov -> post kernels)
     void* d_J;          // [jcap][B][JAC_WORDS]
     int jcap;           // predicts per launch the Jacobian workspace can hold
-    void* d_res;        // [B][8]
     void* d_e;          // [B][24]
     int32_t* d_status;  // [B]
     // Deferred injection: WHETHER an instance's error state still awaits injection is device state (bit
@@ -48,12 +47,11 @@ void free_buffers(dvi_eskf* h) {
     if (h->d_P) (void)hipFree(h->d_P);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_J) (void)hipFree(h->d_J);
-    if (h->d_res) (void)hipFree(h->d_res);
     if (h->d_e) (void)hipFree(h->d_e);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_noise) (void)hipFree(h->d_noise);
     h->d_noise = nullptr;
-    h->d_P = h->d_x = h->d_J = h->d_res = h->d_e = nullptr;
+    h->d_P = h->d_x = h->d_J = h->d_e = nullptr;
     h->d_status = nullptr;
     h->jcap = 0;
 }
@@ -62,11 +60,11 @@ void free_buffers(dvi_eskf* h) {
 bool alloc_buffers(dvi_eskf* h) {
     const size_t es = elem_size(h->dtype);
     const size_t B = (size_t)h->B;
-    h->d_P = h->d_x = h->d_J = h->d_res = h->d_e = nullptr;
+    h->d_P = h->d_x = h->d_J = h->d_e = nullptr;
     h->d_status = nullptr;
     h->jcap = 0;
     if (hipMalloc(&h->d_P, B * 300 * es) != hipSuccess || hipMalloc(&h->d_x, B * 36 * es) != hipSuccess ||
-        hipMalloc(&h->d_J, B * eskf::JAC_WORDS * es) != hipSuccess || hipMalloc(&h->d_res, B * 8 * es) != hipSuccess ||
+        hipMalloc(&h->d_J, B * eskf::JAC_WORDS * es) != hipSuccess ||
         hipMalloc(&h->d_e, B * 24 * es) != hipSuccess ||
         hipMalloc((void**)&h->d_status, B * sizeof(int32_t)) != hipSuccess) {
         free_buffers(h);
@@ -125,7 +123,7 @@ eskf::StepArgs base_args(const dvi_eskf* h) {
     std::memset(&a, 0, sizeof a);
     a.P = h->d_P; a.xs = h->d_x;
     a.P_src = h->d_P; a.xs_src = h->d_x;
-    a.J = h->d_J; a.res = h->d_res; a.e = h->d_e; a.status_ws = h->d_status; a.noise = h->d_noise;
+    a.J = h->d_J; a.e = h->d_e; a.status_ws = h->d_status; a.noise = h->d_noise;
     a.B = h->B;
     a.rounds = 1;
     return a;

@@ -11,7 +11,7 @@ namespace eskf {
 constexpr int DVI_STATUS_SINGULAR = 1;
 constexpr int DVI_STATUS_NONFINITE = 2;
 constexpr int DVI_STATUS_PENDING = 1 << 30;   // workspace word only: the update's error state is not injected yet
-constexpr int JAC_WORDS = 88;
+constexpr int JAC_WORDS = 96;  // words per Jacobian record (eskf_kernels.hip: JW)
 constexpr int NOISE_WORDS = 24; // per-instance noise record: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad   // words per Jacobian record (eskf_kernels.hip: JW)
 
 // constants of one filter configuration, in the kernel's working precision; passed by value
@@ -67,8 +67,8 @@ struct StepArgs {
     void* K_out;        // nullable [B][24][7]
     int32_t* status;    // nullable [B] (caller's)
     // workspace owned by the handle
-    void* J;            // [n_pred][B][88] Jacobian records written by the pre kernel
-    void* res;          // [B][8]  residual (7) + asin-clamp flag
+    void* J;            // [n_pred][B][96] records written by the pre kernel: residual of the update (7 + non-finite flag;
+                        // first predict's record) | Jacobian blocks
     void* e;            // [B][24] error state of the update
     int32_t* status_ws; // [B]
     int64_t B;

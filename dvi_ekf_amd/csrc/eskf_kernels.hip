@@ -53,8 +53,12 @@ __device__ __forceinline__ float t_fma(float a, float b, float c) { return fmaf(
 __device__ __forceinline__ bool t_finite(double a) { return isfinite(a); }
 __device__ __forceinline__ bool t_finite(float a) { return isfinite(a); }
 
+// (cross3, quat_nrm, quat_mul, quat_about_axis: no contraction of a*b+c into an fma -- the error injection is
+//  evaluated by three different kernels (pre kernel on the fly, eskf_pre4_kernel's chains, eskf_post_kernel) and has
+//  to give the same bits in all of them, whatever the surrounding code lets the compiler fuse)
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* c) {
+#pragma clang fp contract(off)
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
     c[2] = a[0] * b[1] - a[1] * b[0];
@@ -80,6 +84,11 @@ __device__ __forceinline__ void mat3_skew(const T* A, const T* w, T* C) {
         C[3 * i + 2] = a0 * w[1] - a1 * w[0];
     }
 }
+template <typename T>
+__device__ __forceinline__ T norm3(const T* v) {
+#pragma clang fp contract(off)
+    return t_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+}
 // Quaternion.rot (tools/Quaternion.py:101-107): rotation matrix of q/|q|, xyzw
 template <typename T>
 __device__ __forceinline__ void quat_to_mat(const T* q, T* M) {
@@ -94,6 +103,7 @@ __device__ __forceinline__ void quat_to_mat(const T* q, T* M) {
 // Quaternion.normalise (Quaternion.py:195-206): unit length, scalar part >= 0
 template <typename T>
 __device__ __forceinline__ void quat_nrm(T* q) {
+#pragma clang fp contract(off)
     T n = T(1) / t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (q[3] < T(0)) n = -n;
 #pragma unroll
@@ -102,6 +112,7 @@ __device__ __forceinline__ void quat_nrm(T* q) {
 // Hamilton product xyzw (Quaternion.py:170-173)
 template <typename T>
 __device__ __forceinline__ void quat_mul(const T* a, const T* b, T* o) {
+#pragma clang fp contract(off)
     T c[3];
     cross3(a, b, c);
     o[3] = a[3] * b[3] - (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]);
@@ -133,6 +144,7 @@ __device__ __forceinline__ void mat_to_quat(const T* M, T* q) {
 // Quaternion.about_axis (Quaternion.py:209-224)
 template <typename T>
 __device__ __forceinline__ void quat_about_axis(T angle, const T* axis, T* q) {
+#pragma clang fp contract(off)
     const T len = t_sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
     T s, c;
     t_sincos(T(0.5) * angle, s, c);
@@ -443,9 +455,17 @@ template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
 
-constexpr int JW = 88;          // words per Jacobian record: A9 Th9 Bm9 Cm18 Dm12 Em9 dt1 | N6 18 | pad
-constexpr int J_A = 0, J_TH = 9, J_BM = 18, J_CM = 27, J_DM = 45, J_EM = 57, J_DT = 66, J_N6 = 67;
-constexpr int J_CORE = 67, J_FULL = 85;
+// One record per instance and predict: the residual of the launch's update (7 words + the non-finite flag; record
+// of the FIRST predict only) followed by the blocks in the member order of Jac<T>:
+//   res8 | A9 Th9 Bm9 Cm18 Dm12 Em9 dt1 | N6 18 | pad      (96 words = 768 B: six 128-byte lines, a group of 64
+//   instances starts on a line of its own)
+constexpr int JW = 96;
+constexpr int J_RES = 0, J_B0 = 8;      // J_B0: first word of the blocks
+constexpr int J_A = J_B0 + 0, J_TH = J_B0 + 9, J_BM = J_B0 + 18, J_CM = J_B0 + 27, J_DM = J_B0 + 45, J_EM = J_B0 + 57,
+              J_DT = J_B0 + 66, J_N6 = J_B0 + 67;
+constexpr int J_CORE = J_B0 + 67, J_FULL = J_B0 + 85;   // record words in use without / with the N6 block
+constexpr int JB_CORE = 67, JB_FULL = 85;               // ... counted from J_B0 (the staging rows of eskf_pre_kernel)
+static_assert(JW == JAC_WORDS, "eskf_device.h sizes the workspace");
 
 // state record, structure-of-arrays: word w of instance b at xs[w * B + b]
 // words: x26 | om_old3 | acc_old3 | q_old4
@@ -580,12 +600,12 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     // overwrites it (block barrier).  Wave 1 stages its 67-word records in LDS (row stride 69:
     // conflict-free) and writes them out as whole records with 16-byte stores -- a lane-per-instance
     // store of an array-of-structures would touch 64 different cache lines per instruction.
-    static_assert(sizeof(Jac<T>) == J_FULL * sizeof(T), "Jac<T> must be the 85-word record");
+    static_assert(sizeof(Jac<T>) == JB_FULL * sizeof(T), "Jac<T> must be the 85 block words of the record");
     // staging rows of 85 words, or 67 when the gyro block of Q is zero and the N6 block is not formed
     // (both odd -> conflict-free); sized by the launcher: 34 KB lets four blocks share a CU
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* sJ = reinterpret_cast<T*>(smem_raw);
-    const int JS = prm.jfull ? J_FULL : J_CORE;
+    const int JS = prm.jfull ? JB_FULL : JB_CORE;
     const int lane = threadIdx.x & 63;
     const bool jac_role = threadIdx.x >= 64;           // wave-uniform
     const int64_t b0 = (int64_t)blockIdx.x * 64;
@@ -673,10 +693,10 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
-            T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW;
+            T* gJ = reinterpret_cast<T*>(a.J) + ((int64_t)ip * a.B + b0) * JW + J_B0;     // (the blocks follow the residual words)
             const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
-            if (prm.jfull) store_records<T, J_FULL>(sJ, gJ, nrec, lane);
-            else store_records<T, J_CORE>(sJ, gJ, nrec, lane);
+            if (prm.jfull) store_records<T, JB_FULL>(sJ, gJ, nrec, lane);
+            else store_records<T, JB_CORE>(sJ, gJ, nrec, lane);
             // (only this wavefront touches the staging rows, and the LDS executes one wavefront's operations in
             //  order: what is needed is that the COMPILER keeps the staging writes, the reads of the store loop
             //  and the next predict's writes in program order -- not a wait for outstanding vector-memory
@@ -719,7 +739,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         if (nv > T(1)) { nv = T(1); flag = T(1); }
         const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
         const T f = (nv == T(0)) ? T(0) : ang / nv;
-        T* gr = reinterpret_cast<T*>(a.res) + bo * 8;
+        T* gr = reinterpret_cast<T*>(a.J) + bo * JW + J_RES;      // (record of the launch's first predict)
         T r[7];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { r[i] = gpos[i] - s.pc[i]; r[3 + i] = f * qe[i]; }
@@ -748,7 +768,9 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
 //       Theta, dt
 //   W3  sincos(q3), sincos(phi), sincos(phi+)                         R_BC+ and its derivatives -> blocks Dm, Em
 //
-// then barrier 2 and all four wavefronts move the 64 staged records to HBM.  The eight sincos evaluations of a
+// (barrier 1b, right behind 1: every wavefront has copied the trigonometry out of the staging rows, whose block words
+// carry it between the two) then barrier 2 and all four wavefronts move the 64 staged records -- the residual of the
+// update in front, then the blocks -- to HBM.  The eight sincos evaluations of a
 // pair step (two injections, four joint angles, phi after the predict, the notch measurement) -- a third of the
 // old kernel's dependent chain -- are spread two per wavefront, and every chain fits 128 VGPRs (four blocks per CU,
 // sixteen wavefronts; the two-role kernel above needs 217 and runs at two per SIMD).  Same helper functions, same
@@ -759,13 +781,13 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
 // ----------------------------------------------------------------------------------
 #ifdef ESKF_X_STAMPS        // diagnostic build only: wall-clock stamps (100 MHz) of every block of the last pre4 launch
 __device__ unsigned long long g_x_stamps[8 * 4096];
-#define ESKF_STAMP(K) { if (lane == 0 && blockIdx.x < 4096) g_x_stamps[(K) * 4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime(); }
+#define ESKF_STAMP(K) { if (lane == 0 && vblock < 4096) g_x_stamps[(K) * 4096 + vblock] = __builtin_amdgcn_s_memrealtime(); }
 hipError_t x_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x_stamps), sizeof(g_x_stamps)); }
 #else
 #define ESKF_STAMP(K) {}
 #endif
-constexpr int PRE4_TRIG = 10;       // s1 c1 s2 c2 | s3 c3 sp cp sp+ cp+
-constexpr int PRE4_XW = PRE4_TRIG + 3;   // + r_p (3): 64 x (67 + 13) words = 40 960 B, four blocks per CU exactly
+// exchange words of a lane sit in its own staging row, on block words that are only written after barrier 1b
+constexpr int PRE4_XOFF = J_BM;
 template <typename T>
 __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0, int n, T* dst) {
 #pragma unroll
@@ -776,14 +798,12 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
 #endif
 }
 template <typename T>
-__global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams<T> prm) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock) {
     T* sJ = reinterpret_cast<T*>(smem_raw);
-    const int JS = prm.jfull ? J_FULL : J_CORE;
-    T* sX = sJ + 64 * JS;                              // [PRE4_XW][64] exchange words, lane-contiguous
+    const int JS = prm.jfull ? J_FULL : J_CORE;        // staging rows = whole records: residual words, then the blocks (odd: conflict-free)
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x >> 6;                 // wave-uniform
-    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    const int64_t b0 = (int64_t)vblock * 64;
     const int64_t b_raw = b0 + lane;
     const bool live = b_raw < a.B;
     const int64_t b = live ? b_raw : a.B - 1;          // tail lanes recompute the last instance, write nothing
@@ -791,7 +811,7 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
     T* xo = reinterpret_cast<T*>(a.xs);
     const int64_t B = a.B;
 #ifdef ESKF_X_STAGGER       // experiment: every other block starts ESKF_X_STAGGER x 0.5 us late
-    if (blockIdx.x & 1) {
+    if (vblock & 1) {
         for (int k = 0; k < ESKF_X_STAGGER; ++k) __builtin_amdgcn_s_sleep(16);
     }
 #endif
@@ -802,7 +822,14 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
     const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
     const bool inject_now = was_pending && !a.drop_pending && !(pend_status & DVI_STATUS_SINGULAR);
     const T dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? b : 0];
-    Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);    // this lane's staging row (W2, W3)
+    T* row = sJ + lane * JS;                                   // this lane's staging row
+    Jac<T>& J = *reinterpret_cast<Jac<T>*>(row + J_B0);        // its blocks (W2, W3)
+    T* xw = row + PRE4_XOFF;                                   // exchange words (trigonometry): on Bm / Cm, which W2 only forms after barrier 1b
+    // the non-finite flag of the residual is OR-ed together by W0 (r_p) and W1 (the rest); W2 clears it before barrier 1
+    auto raise_flag = [&]() {
+        if constexpr (sizeof(T) == 8) __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(row + J_RES + 7), 0x3ff0000000000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_or(reinterpret_cast<unsigned*>(row + J_RES + 7), 0x3f800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
     if (role == 0) ESKF_STAMP(0)
 
     if (role == 0) {
@@ -833,7 +860,7 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
         ESKF_STAMP(1)
         if (inject_now) {                               // state.py:46-60,105-129
             T th[3] = {e9[6], e9[7], e9[8]}, dq[4], qn[4];
-            quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
+            quat_about_axis(norm3(th), th, dq);
             quat_mul(q, dq, qn);
             quat_nrm(qn);
 #pragma unroll
@@ -857,8 +884,9 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
         __syncthreads();                                // barrier 1: old state read by everyone, trigonometry published
         ESKF_STAMP(3)
         ProbeTrig<T> t;
-        t.s1 = sX[0 * 64 + lane]; t.c1 = sX[1 * 64 + lane]; t.s2 = sX[2 * 64 + lane]; t.c2 = sX[3 * 64 + lane];
-        t.s3 = sX[4 * 64 + lane]; t.c3 = sX[5 * 64 + lane];
+        t.s1 = xw[0]; t.c1 = xw[1]; t.s2 = xw[2]; t.c2 = xw[3];
+        t.s3 = xw[4]; t.c3 = xw[5];
+        __syncthreads();                                // barrier 1b: everyone holds the trigonometry, the rows may be written
         T pB[3];
         {
             T z6[3], e5[3], e6[3];
@@ -882,7 +910,10 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
         }
         if (a.do_update) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) sX[(PRE4_TRIG + i) * 64 + lane] = rp[i];
+            for (int i = 0; i < 3; ++i) row[J_RES + i] = rp[i];
+            // a NaN / inf measurement or state propagates exactly as it does in the reference (NumPy arithmetic, no
+            // check); the instance is flagged, its neighbours are not affected
+            if (!t_finite(rp[0] + rp[1] + rp[2])) raise_flag();
         }
         if (live) {
 #pragma unroll
@@ -912,7 +943,7 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
         }
         if (inject_now) {
             T dqc[4], qcn[4];
-            quat_about_axis(t_sqrt(e2124[0] * e2124[0] + e2124[1] * e2124[1] + e2124[2] * e2124[2]), e69, dqc);   // sic (state.py:124)
+            quat_about_axis(norm3(e2124), e69, dqc);   // sic (state.py:124)
             quat_mul(qc, dqc, qcn);
             quat_nrm(qcn);
 #pragma unroll
@@ -931,8 +962,9 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
         }
         __syncthreads();                                // barrier 1
         ProbeTrig<T> t;
-        t.s1 = sX[0 * 64 + lane]; t.c1 = sX[1 * 64 + lane]; t.s2 = sX[2 * 64 + lane]; t.c2 = sX[3 * 64 + lane];
-        t.sp = sX[6 * 64 + lane]; t.cp = sX[7 * 64 + lane];
+        t.s1 = xw[0]; t.c1 = xw[1]; t.s2 = xw[2]; t.c2 = xw[3];
+        t.sp = xw[6]; t.cp = xw[7];
+        __syncthreads();                                // barrier 1b
         T RBC[9], z6[3];
         {
             T aa[3], g[3];
@@ -976,19 +1008,14 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
 #pragma unroll
             for (int i = 0; i < 4; ++i) xo[(22 + i) * B + b] = qcn[i];
         }
-        __syncthreads();                                // barrier 2 (r_p is there)
-        if (live) {
-            if (a.do_update) {
-                const T r0 = sX[(PRE4_TRIG + 0) * 64 + lane], r1 = sX[(PRE4_TRIG + 1) * 64 + lane], r2 = sX[(PRE4_TRIG + 2) * 64 + lane];
-                // a NaN / inf measurement or state propagates exactly as it does in the reference (NumPy
-                // arithmetic, no check); the instance is flagged, its neighbours are not affected
-                if (!t_finite(r0 + r1 + r2 + r[0] + r[1] + r[2] + r[3])) flag = T(1);
-                T* gr = reinterpret_cast<T*>(a.res) + b * 8;
-                gr[0] = r0; gr[1] = r1; gr[2] = r2; gr[3] = r[0]; gr[4] = r[1]; gr[5] = r[2]; gr[6] = r[3];
-                gr[7] = flag;                                     // asin argument was clamped, or non-finite residual
-            }
-            if (was_pending) a.status_ws[b] = pend_status & ~DVI_STATUS_PENDING;      // the injection is done (or dropped)
+        if (a.do_update) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) row[J_RES + 3 + i] = r[i];
+            if (!t_finite(r[0] + r[1] + r[2] + r[3])) flag = T(1);
+            if (flag != T(0)) raise_flag();                       // asin argument was clamped, or non-finite residual
         }
+        if (live && was_pending) a.status_ws[b] = pend_status & ~DVI_STATUS_PENDING;  // the injection is done (or dropped)
+        __syncthreads();                                // barrier 2: the 64 staged records are complete
     } else {
         // ---- W2 / W3: Jacobian blocks (Filter.py:249-342), evaluated at the post-predict dofs / notch with the
         // pre-predict buffers om_old, acc_old, R_WB_old
@@ -1034,7 +1061,8 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
             T s1, c1, s2, c2;
             t_sincos(q1n, s1, c1);
             t_sincos(q2n, s2, c2);
-            sX[0 * 64 + lane] = s1; sX[1 * 64 + lane] = c1; sX[2 * 64 + lane] = s2; sX[3 * 64 + lane] = c2;
+            xw[0] = s1; xw[1] = c1; xw[2] = s2; xw[3] = c2;
+            row[J_RES + 7] = T(0);                      // (the residual's flag word: raised by W0 / W1 after barrier 1b)
             quat_to_mat(qo, Ro);
             J.dt = dt;
             T w[3];
@@ -1054,15 +1082,19 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
             t_sincos(phi, sp, cp);
             if (phi_n == phi) { spn = sp; cpn = cp; }
             else t_sincos(phi_n, spn, cpn);
-            sX[4 * 64 + lane] = s3; sX[5 * 64 + lane] = c3; sX[6 * 64 + lane] = sp; sX[7 * 64 + lane] = cp;
-            sX[8 * 64 + lane] = spn; sX[9 * 64 + lane] = cpn;
+            xw[4] = s3; xw[5] = c3; xw[6] = sp; xw[7] = cp;
+            xw[8] = spn; xw[9] = cpn;
         }
         __syncthreads();                                // barrier 1
         ProbeTrig<T> t;                                 // at the post-predict dofs / notch
-        t.s1 = zeroed[0] ? T(0) : sX[0 * 64 + lane]; t.c1 = zeroed[0] ? T(1) : sX[1 * 64 + lane];
-        t.s2 = zeroed[1] ? T(0) : sX[2 * 64 + lane]; t.c2 = zeroed[1] ? T(1) : sX[3 * 64 + lane];
-        t.s3 = zeroed[2] ? T(0) : sX[4 * 64 + lane]; t.c3 = zeroed[2] ? T(1) : sX[5 * 64 + lane];
-        t.sp = sX[8 * 64 + lane]; t.cp = sX[9 * 64 + lane];
+        {
+            const T s1 = xw[0], c1 = xw[1], s2 = xw[2], c2 = xw[3], s3 = xw[4], c3 = xw[5];
+            t.s1 = zeroed[0] ? T(0) : s1; t.c1 = zeroed[0] ? T(1) : c1;
+            t.s2 = zeroed[1] ? T(0) : s2; t.c2 = zeroed[1] ? T(1) : c2;
+            t.s3 = zeroed[2] ? T(0) : s3; t.c3 = zeroed[2] ? T(1) : c3;
+            t.sp = xw[8]; t.cp = xw[9];
+        }
+        __syncthreads();                                // barrier 1b
         const T thd = notch[1];
         T om_t[3];
 #pragma unroll
@@ -1183,14 +1215,19 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
     if (role == 0) ESKF_STAMP(7)
 #endif
 }
+template <typename T>
+__global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams<T> prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    pre4_body<T>(a, prm, smem_raw, (int)blockIdx.x);
+}
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
 template <typename T>
 __device__ __forceinline__ void inject_error(State<T>& s, const T* e) {
     T th[3] = {e[6], e[7], e[8]}, thc[3] = {e[21], e[22], e[23]};
     T dq[4], dqc[4], qn[4], qcn[4];
-    quat_about_axis(t_sqrt(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]), th, dq);
-    quat_about_axis(t_sqrt(thc[0] * thc[0] + thc[1] * thc[1] + thc[2] * thc[2]), th, dqc);   // sic (state.py:124)
+    quat_about_axis(norm3(th), th, dq);
+    quat_about_axis(norm3(thc), th, dqc);   // sic (state.py:124)
     quat_mul(s.q, dq, qn);
     quat_nrm(qn);
     quat_mul(s.qc, dqc, qcn);
@@ -1267,8 +1304,8 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
     T* sJ = smem + grp * REGION + OFF_J;
     T* sE = smem + grp * REGION + OFF_E;
 
-    const int jwords = prm.q_gyro ? J_FULL : J_CORE;
-    constexpr int NJ = (J_FULL + LPI - 1) / LPI;     // Jacobian words per lane (upper bound)
+    const int jwords = prm.q_gyro ? JB_FULL : JB_CORE;     // (block words: the LDS copy starts at J_B0)
+    constexpr int NJ = (JB_FULL + LPI - 1) / LPI;     // Jacobian words per lane (upper bound)
     constexpr int NV = (150 + LPI - 1) / LPI;        // 16-byte (2-word) pieces of packed P per lane
     using T2 = typename Vec2<T>::type;
 
@@ -1287,7 +1324,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
             if (e2 < 150) pv[k] = gP2_[e2];                                                        \
         }                                                                                          \
         if (a.n_pred > 0) {                                                                        \
-            const T* gJ_ = reinterpret_cast<const T*>(a.J) + (INST) * JW;                          \
+            const T* gJ_ = reinterpret_cast<const T*>(a.J) + (INST) * JW + J_B0;                          \
             _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                       \
                 const int e = lig + k * LPI;                                                       \
                 if (e < jwords) jv[k] = gJ_[e];                                                    \
@@ -1335,7 +1372,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
     // ================================ predict(s) =======================================
     for (int ip = 0; ip < a.n_pred; ++ip) {
         if (ip > 0) {   // (the record of the first predict was fetched together with P)
-            const T* gJ = reinterpret_cast<const T*>(a.J) + ((int64_t)ip * a.B + inst) * JW;
+            const T* gJ = reinterpret_cast<const T*>(a.J) + ((int64_t)ip * a.B + inst) * JW + J_B0;
             T jv[NJ];
 #pragma unroll
             for (int k = 0; k < NJ; ++k) {
@@ -1349,13 +1386,13 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
             }
         }
         group_sync();
-        const T dt = sJ[J_DT];
-        const T* A = sJ + J_A;
-        const T* Th = sJ + J_TH;
-        const T* Bm = sJ + J_BM;
-        const T* Cm = sJ + J_CM;
-        const T* Dm = sJ + J_DM;
-        const T* Em = sJ + J_EM;
+        const T dt = sJ[J_DT - J_B0];
+        const T* A = sJ + J_A - J_B0;
+        const T* Th = sJ + J_TH - J_B0;
+        const T* Bm = sJ + J_BM - J_B0;
+        const T* Cm = sJ + J_CM - J_B0;
+        const T* Dm = sJ + J_DM - J_B0;
+        const T* Em = sJ + J_EM - J_B0;
 
         // ---- phase 1: lane owns column j.  U[:,j] = Fx[18:24,:] P[:,j]; then the row
         // operations of Faa = Fx[0:18,0:18] on column j (rows 0:9, 15, 16), all from the
@@ -1446,7 +1483,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 for (int k = 0; k < 3; ++k) y += Em[3 * b2 + k] * u[19 + k];
                 if (b2 >= 1) y += u[21 + b2];   // the (22,22) and (23,23) ones of the identity survive
                 if (prm.q_gyro) {   // camera block of Fi Q Fi^T (gyro noise enters rows 18:24 through N6)
-                    const T* N6 = sJ + J_N6;
+                    const T* N6 = sJ + J_N6 - J_B0;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const T nk = N6[3 * a2 + k] * (PIN ? reinterpret_cast<const T*>(a.noise)[inst * NOISE_WORDS + 3 + k] : prm.qd[3 + k]);
@@ -1475,7 +1512,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 row[16] = u[16] + dt * u[17];
                 row[17] = u[17];
                 if (prm.q_gyro) {   // Fi[6:9,3:6] = I couples the gyro noise into the camera rows
-                    const T* N6 = sJ + J_N6;
+                    const T* N6 = sJ + J_N6 - J_B0;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) row[6 + k] += N6[3 * ar + k] * (PIN ? reinterpret_cast<const T*>(a.noise)[inst * NOISE_WORDS + 3 + k] : prm.qd[3 + k]);
                 }
@@ -1519,7 +1556,7 @@ __global__ __launch_bounds__(64) void eskf_cov_kernel(StepArgs a, DevParams<T> p
                 }
             }
         }
-        const T* gres = reinterpret_cast<const T*>(a.res) + inst * 8;
+        const T* gres = reinterpret_cast<const T*>(a.J) + inst * JW + J_RES;
         T res[7];
 #pragma unroll
         for (int m = 0; m < 7; ++m) res[m] = gres[m];
@@ -1684,8 +1721,9 @@ constexpr int R_RES = 744;         // residual of the update (7) + non-finite fl
 // then continue each other's bank pattern (row stride 25: lane t of the block hits bank 25 t mod 32)
 constexpr int R_REGION = 760;
 constexpr int R_REGION_PIN = 792;  // with per-instance noise
+constexpr int L_DUMP = 71;         // record words that have no place in the LDS copy (the residual) land on this pad word
 __device__ __forceinline__ int lds_word(int e) {   // HBM record word -> LDS word
-    return e + (e >= J_TH) + (e >= J_BM) + (e >= J_CM) + (e >= J_DT) + (e >= J_N6);
+    return e < J_B0 ? L_DUMP : (e - J_B0) + (e >= J_TH) + (e >= J_BM) + (e >= J_CM) + (e >= J_DT) + (e >= J_N6);
 }
 
 // o = Fx v  (Fx of Filter.py:270-342 with the structure of SURVEY.md App. A; same blocks as
@@ -2196,9 +2234,9 @@ constexpr RowsTables make_rows_tables() {
                 t.pos[v][l][2 * k + 1] = packed_image_pos(2 * e2 + 1);
             }
             for (int k = 0; k < 4; ++k) {
-                const int wr = l + lpi * k, w = wr < 88 ? wr : 87;
+                const int wr = l + lpi * k, w = wr < JW ? wr : JW - 1, b = w - J_B0;
                 t.jsrc[v][l][k] = w;
-                t.jdst[v][l][k] = w + (w >= 9) + (w >= 18) + (w >= 27) + (w >= 66) + (w >= 67);
+                t.jdst[v][l][k] = w < J_B0 ? 71 : b + (b >= 9) + (b >= 18) + (b >= 27) + (b >= 66) + (b >= 67);
             }
         }
     }
@@ -2222,8 +2260,9 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
-template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false>
-__global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
+template <typename T, bool PIN, int LPI, bool SLIM>
+__device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams<T>& prm, T* smem, const int vblock, const int lane) {
+    auto gsync = [&]() { group_sync(); };
     using namespace rowk;
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
     static_assert(!SLIM || LPI == 32, "SLIM: 32 lanes per instance");
@@ -2234,9 +2273,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     constexpr int R_C = SLIM ? 600 : rowk::R_C;
     constexpr int R_RES = SLIM ? 624 : rowk::R_RES;
     constexpr int R_J = SLIM ? 0 : rowk::R_J;      // (SLIM: never addressed)
-    __shared__ __attribute__((aligned(16))) T smem[G * REGION];
 
-    const int lane = threadIdx.x;
     const int grp = LPI == 32 ? (lane >> 5) : (lane / 24);
     const int lig = LPI == 32 ? (lane & 31) : (lane - 24 * grp);
     const bool active = LPI == 24 || lig < 24;
@@ -2249,7 +2286,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     const T* sN = sR + 8;                   // PIN: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
     // last word of the record in use (dt without the gyro block of Q, else the end of N6) and its LDS slot
     const int jlast = prm.q_gyro ? J_FULL - 1 : J_CORE - 1;
-    const int jlast_lds = prm.q_gyro ? L_N6 + 17 : L_DT;
+    const int jlast_lds = prm.q_gyro ? L_N6 + 17 : L_DUMP;   // (everything past dt goes to the pad word)
     constexpr int NJ = (JW + LPI - 1) / LPI;
     constexpr int NV = (150 + LPI - 1) / LPI;
     using T2 = typename Vec2<T>::type;
@@ -2260,7 +2297,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     // Instance indices are 32-bit (the launcher refuses B >= 2^31) and opaque: byte addresses are
     // formed where they are used instead of being kept in registers from the prologue on.
     const int nB = (int)a.B;
-    const int slot = (int)blockIdx.x * G + grp;
+    const int slot = vblock * G + grp;
     // Jacobian record IP of instance INST and the residual of the update -> registers -> LDS.  No
     // predicates either: every lane moves three record words (the 88-word record is padded; what
     // lies beyond the blocks in use lands in the idle N6 area) and one residual word.
@@ -2273,7 +2310,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
             const int w_ = LPI == 32 ? lj_ + 32 * k : kRowsTables.jsrc[TV][lj_][k];   /* (same numbers) */ \
             DST[k] = gJ_[w_ < jlast ? w_ : jlast];   /* (the padding of the record is not fetched) */ \
         }                                                                                          \
-        RES.x = reinterpret_cast<const T*>(a.res)[(int64_t)(INST) * 8 + (lj_ & 7)];                \
+        RES.x = (reinterpret_cast<const T*>(a.J) + (int64_t)(INST) * JW + J_RES)[lj_ & 7];                     \
         if (PIN) RES.y = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + (lj_ < 24 ? lj_ : 23)]; \
     }
     // 32 lanes per instance: the record stays in the registers it was fetched into and is
@@ -2304,7 +2341,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     {                                                                                              \
             /* wave-uniform base (scalar registers) + an unsigned 32-bit lane offset: one address  \
                instruction per load instead of a sign extension and a 64-bit add */                \
-            const int i0_ = (int)blockIdx.x * G;                                                   \
+            const int i0_ = vblock * G;                                                   \
             const T* gPw_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300;              \
             const unsigned io_ = (unsigned)(inst - i0_) * (300u * 8u);                             \
             /* byte offset of P[row][j] = P[max][min]: packed row hi starts at word 25 hi (hi < 12) or    \
@@ -2326,7 +2363,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
         if (sizeof(T) == 8) {                                                                      \
             /* wave-uniform base (scalar registers) + an unsigned 32-bit lane offset: one address  \
                instruction per load instead of a sign extension and a 64-bit add */                \
-            const int i0_ = (int)blockIdx.x * G;                                                   \
+            const int i0_ = vblock * G;                                                   \
             const T* gPw_ = reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300;              \
             const unsigned io_ = (unsigned)(inst - i0_) * (300u * 8u);                             \
             /* byte offset of P[row][j] = P[max][min]: packed row hi starts at word 25 hi (hi < 12) or    \
@@ -2341,7 +2378,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                 const unsigned o_ = ((unsigned)j <= rw_) ? va_ + 8u * (unsigned)j : vb_ + cj_;     \
                 p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
             }                                                                                      \
-            group_sync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
+            gsync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
         } else {                                                                                   \
             const T2* gP2_ = reinterpret_cast<const T2*>(gP_);                                     \
             T2 pv_[NV];                                                                            \
@@ -2356,9 +2393,9 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                 sB[off_[2 * k]] = pv_[k].x;                                                        \
                 sB[off_[2 * k + 1]] = pv_[k].y;                                                    \
             }                                                                                      \
-            group_sync();                                                                          \
+            gsync();                                                                          \
             _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[gat_[j]];                     \
-            group_sync();                                                                          \
+            gsync();                                                                          \
         }                                                                                          \
     }
     // one predict on the row-resident P with the Jacobian record that sits in LDS
@@ -2366,11 +2403,11 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     {                                                                                              \
         if constexpr (DPPJ) fx_apply_store_dpp(Jr, p, sB + row * PS, active);                      \
         else fx_apply_store(sJ, p, sB + row * PS, active);   /* column `row` of Fx P = row `row` of W = P Fx^T */ \
-        group_sync();                                                                              \
+        gsync();                                                                              \
         if constexpr (DPPJ) fx_apply_col_dpp(Jr, sB + row, p);                                     \
         else fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */     \
         noise_rows<T, PIN, !SLIM>(prm, sJ, sN, row, p);                                            \
-        group_sync();                                                                              \
+        gsync();                                                                              \
     }
     const bool valid = slot < nB;           // tail: recompute the last instance, write nothing
     int inst = valid ? slot : nB - 1;
@@ -2387,7 +2424,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
         ESKF_ISSUE_ROW()
         ESKF_LOAD_J(j0, r0, inst, 0)
         ESKF_STAGE_J(j0, r0)
-        group_sync();       // (the staged residual is visible to every lane)
+        gsync();       // (the staged residual is visible to every lane)
     } else {
         {   // first Jacobian record and residual into LDS, packed covariance into registers
             T j0[NJ];
@@ -2414,7 +2451,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
             ESKF_PREDICT_ROWS()
             if (more) {
                 ESKF_STAGE_J(jn, rn)
-                group_sync();
+                gsync();
             }
         }
     } else {
@@ -2425,7 +2462,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                 rn.x = rn.y = T(0);
                 ESKF_LOAD_J(jn, rn, inst, ip)
                 ESKF_STAGE_J(jn, rn)
-                group_sync();
+                gsync();
             }
             ESKF_PREDICT_ROWS()
         }
@@ -2490,7 +2527,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                 pin_row(p);
                 asm volatile("" : "+v"(e), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
             });
-            if (__builtin_expect(fail, 0)) group_sync();   // (the published columns are read below)
+            if (__builtin_expect(fail, 0)) gsync();   // (the published columns are read below)
         } else {
 #pragma unroll
         for (int m = 0; m < 7; ++m) {
@@ -2498,7 +2535,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                                             //  stay there for the take-back)
             const T pm = p[sel[m]];
             if (active) cb[row] = pm;       // column sel_m of the current P
-            group_sync();
+            gsync();
             // upper half of the column first: it holds the measured components
             T c[12];
 #pragma unroll
@@ -2552,7 +2589,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
             sC[row] = e;
             if (valid) reinterpret_cast<T*>(a.e)[(int64_t)inst * 24 + row] = e;
         }
-        group_sync();
+        gsync();
         T* sY = sB;     // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
         if (upd) {
             // ---- reset G P G^T (Filter.py:387-390), G = I - [theta/2]x on 6:9 and 21:24.
@@ -2576,7 +2613,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                 }
             }
         }
-        group_sync();
+        gsync();
         // row part: only rows 6:9 and 21:24 change.  For a column j outside those blocks
         // P_new[i][j] = P_new[j][i], which lane j already holds (its column result); inside
         // them the 3x3 row combination of the column results of the lane's own triple.
@@ -2601,7 +2638,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
                 }
             }
         }
-        group_sync();
+        gsync();
         if (lig == 0 && valid) {
             a.status_ws[inst] = status | DVI_STATUS_PENDING;   // the error state of this update awaits injection
             if (a.status) a.status[inst] = status;
@@ -2613,7 +2650,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 #pragma unroll
         for (int j = 0; j < 24; ++j) lds_store1(sB + row * PS + j, p[j]);
     }
-    group_sync();
+    gsync();
     if (valid) {
         // (all the reads of the image first, then the stores: read-wait-store per piece is five LDS round trips
         //  in a row at the very end of the wavefront's life; the last piece's index is clamped instead of
@@ -2637,6 +2674,14 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 #undef ESKF_UNPACK_ROW
 #undef ESKF_ISSUE_ROW
 #undef ESKF_PREDICT_ROWS
+}
+
+template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false>
+__global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
+    constexpr int G = LPI == 32 ? 2 : 8;
+    constexpr int REGION = SLIM ? (PIN ? 664 : 640) : PIN ? rowk::R_REGION_PIN : rowk::R_REGION;
+    __shared__ __attribute__((aligned(16))) T smem[G * REGION];
+    cov_rows_body<T, PIN, LPI, SLIM>(a, prm, smem, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // state.dofs of every instance (Filter.calculate_dof_metric, Filter.py:452-455; the payload of the final gather)
@@ -2961,9 +3006,9 @@ template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
-    const size_t stage_bytes = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + 9) * sizeof(T);    // + parked measurement
+    const size_t stage_bytes = (size_t)64 * ((prm.jfull ? JB_FULL : JB_CORE) + 9) * sizeof(T);    // + parked measurement
     if (a.n_pred == 1 && !g_pre_legacy) {
-        const size_t stage4 = (size_t)64 * ((prm.jfull ? J_FULL : J_CORE) + PRE4_XW) * sizeof(T);
+        const size_t stage4 = (size_t)64 * (prm.jfull ? J_FULL : J_CORE) * sizeof(T);
         hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
     } else if (a.n_pred == 1)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);

@@ -25,9 +25,11 @@ from oracle import c_oracle
 CHECKPOINTS = (100, 1000, 9900, 10000)
 FP64_TOL = 1e-9
 # fp32 vs fp64: max over instances of |dx| / max(1, |x|) and of |dP| / max|P|  -- the stated fp32 tolerance of the path
-# (measured: 1.2e-6 / 1.5e-6 at step 100, 5.0e-6 / 6.6e-5 at step 1 000, 3.3e-3 / 5.2e-6 over the last hundred steps, where
-#  the dynamics amplify a perturbation ~400x per hundred steps: the fp64-vs-oracle figure there is 4e-14)
-FP32_TOL = {100: (1e-5, 1e-4), 1000: (5e-5, 1e-3), "last100": (2e-2, 1e-4)}
+# (measured: 1.2e-6 / 1.5e-6 at step 100, 5.0e-6 / 6.6e-5 at step 1 000, 3.3e-3 ... 4.3e-2 / 5.2e-6 ... 1.1e-5 over the last
+#  hundred steps, where the dynamics amplify a perturbation ~400x per hundred steps -- the fp64-vs-oracle figure there is
+#  1e-12 -- and the worst instance of 8 192 depends on which way single roundings fall: two builds that differ in where
+#  a product is fused into an fma gave 3.3e-3 and 4.3e-2)
+FP32_TOL = {100: (1e-5, 1e-4), 1000: (5e-5, 1e-3), "last100": (1e-1, 1e-4)}
 
 
 def _segments(f, wl, om, acc, dev, checkpoints, first=0, flagged=None):

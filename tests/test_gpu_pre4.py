@@ -55,3 +55,4 @@ def test_pre4_agrees_with_two_role_pre_kernel(tmp_path, scenario):
         assert worst[key] <= tol * eps, (key, worst[key])
     print(scenario, {k: f"{v:.1e}" for k, v in worst.items()})
     assert (a["st1"][[5, 7, 9]] & 2).all()          # the non-finite measurements were flagged (on both sides)
+
