@@ -2035,6 +2035,7 @@ __device__ __forceinline__ void spread_rows(double v, double& X, double& Y) {
 // operands, free to be interleaved with independent chains.
 template <int LANE, bool FIRST = false>
 __device__ __forceinline__ void dpp_fmac(double& acc, double src, double mul) {
+    if constexpr (FIRST) acc = 0.0;     // (the accumulator's first term: whatever it held is not read)
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
 }
 template <int LANE>
@@ -2053,6 +2054,7 @@ __device__ __forceinline__ void spread_rows(float v, float& X, float& Y) {
 }
 template <int LANE, bool FIRST = false>
 __device__ __forceinline__ void dpp_fmac(float& acc, float src, float mul) {
+    if constexpr (FIRST) acc = 0.0f;
     asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
 }
 template <int LANE>
@@ -2206,6 +2208,21 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
 #pragma unroll
     for (int r = 0; r < 3; ++r) { o[18 + r] = u[r]; o[21 + r] = w[r]; }
 }
+// (row >= J) ? a : b for the 32-lanes-per-instance layout, where row = min(lane & 31, 23): the lanes with
+// row >= J are a compile-time constant, so the select takes its condition from a scalar register pair instead of a
+// vector compare (one VALU instruction per row element saved in front of the 24 row loads).  Any other layout
+// compares with the lane's `row`.
+template <bool LANES32>
+__device__ __forceinline__ unsigned select_lanes_ge(int J, unsigned a, unsigned b, unsigned row) {
+    if constexpr (!LANES32) return ((unsigned)J <= row) ? a : b;     // (24 lanes per instance: rows straddle wavefronts)
+    if (J <= 0) return a;
+    const unsigned m32 = J >= 24 ? 0u : ~((1u << J) - 1u);
+    const unsigned long long mask = ((unsigned long long)m32 << 32) | m32;
+    unsigned r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(mask));
+    (void)row;
+    return r;
+}
 }  // namespace rowk
 
 // Index tables of the row-resident kernel, computed at compile time and read from device memory (a few
@@ -2310,7 +2327,8 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             const int w_ = LPI == 32 ? lj_ + 32 * k : kRowsTables.jsrc[TV][lj_][k];   /* (same numbers) */ \
             DST[k] = gJ_[w_ < jlast ? w_ : jlast];   /* (the padding of the record is not fetched) */ \
         }                                                                                          \
-        RES.x = (reinterpret_cast<const T*>(a.J) + (int64_t)(INST) * JW + J_RES)[lj_ & 7];                     \
+        /* (32 lanes per instance: the residual is words 0..7 of the first record, i.e. already in DST[0]) */ \
+        if constexpr (LPI != 32) RES.x = (reinterpret_cast<const T*>(a.J) + (int64_t)(INST) * JW + J_RES)[lj_ & 7]; \
         if (PIN) RES.y = reinterpret_cast<const T*>(a.noise)[(int64_t)(INST) * NOISE_WORDS + (lj_ < 24 ? lj_ : 23)]; \
     }
     // 32 lanes per instance: the record stays in the registers it was fetched into and is
@@ -2329,7 +2347,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
                 sJ[w_ < jlast_lds ? w_ : jlast_lds] = SRC[k];                                      \
             }                                                                                      \
         }                                                                                          \
-        sR[lig & 7] = RES.x;            /* (several lanes, same value) */                          \
+        if constexpr (!DPPJ) sR[lig & 7] = RES.x;       /* (several lanes, same value) */          \
         if (PIN) sR[8 + (lig < 24 ? lig : 23)] = RES.y;                                            \
     }
     // row `row` of P from the packed record.  fp64: 24 eight-byte loads per lane with per-lane addresses (the
@@ -2353,7 +2371,10 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             const unsigned vb_ = io_ + 8u * rw_;                                                   \
             _Pragma("unroll") for (int j = 0; j < 24; ++j) {                                       \
                 const unsigned cj_ = 8u * (unsigned)(j < 12 ? 25 * j : 26 * (23 - j) + 1);         \
-                const unsigned o_ = ((unsigned)j <= rw_) ? va_ + 8u * (unsigned)j : vb_ + cj_;     \
+                /* (j <= row) ? va + 8 j : vb + c_j  as  select(vb + (c_j - 8 j), va) + 8 j: which lanes hold a     \
+                   row >= j is a CONSTANT of the lane layout -- handed to the select as a scalar mask, no       \
+                   compare; the + 8 j rides in the load's offset field */                                      \
+                const unsigned o_ = rowk::select_lanes_ge<LPI == 32>(j, va_, vb_ + (cj_ - 8u * (unsigned)j), rw_) + 8u * (unsigned)j; \
                 p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
             }                                                                                      \
     }
@@ -2375,7 +2396,10 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             const unsigned vb_ = io_ + 8u * rw_;                                                   \
             _Pragma("unroll") for (int j = 0; j < 24; ++j) {                                       \
                 const unsigned cj_ = 8u * (unsigned)(j < 12 ? 25 * j : 26 * (23 - j) + 1);         \
-                const unsigned o_ = ((unsigned)j <= rw_) ? va_ + 8u * (unsigned)j : vb_ + cj_;     \
+                /* (j <= row) ? va + 8 j : vb + c_j  as  select(vb + (c_j - 8 j), va) + 8 j: which lanes hold a     \
+                   row >= j is a CONSTANT of the lane layout -- handed to the select as a scalar mask, no       \
+                   compare; the + 8 j rides in the load's offset field */                                      \
+                const unsigned o_ = rowk::select_lanes_ge<LPI == 32>(j, va_, vb_ + (cj_ - 8u * (unsigned)j), rw_) + 8u * (unsigned)j; \
                 p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
             }                                                                                      \
             gsync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
@@ -2424,7 +2448,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         ESKF_ISSUE_ROW()
         ESKF_LOAD_J(j0, r0, inst, 0)
         ESKF_STAGE_J(j0, r0)
-        gsync();       // (the staged residual is visible to every lane)
+        if (PIN || !SLIM) gsync();      // (what has been staged -- noise record, N6 rows -- is visible to every lane)
     } else {
         {   // first Jacobian record and residual into LDS, packed covariance into registers
             T j0[NJ];
@@ -2434,6 +2458,14 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             ESKF_STAGE_J(j0, r0)
         }
         ESKF_UNPACK_ROW()
+    }
+    // 32 lanes per instance: residual (7) and non-finite flag of the update are words 0..7 of the first predict's
+    // record -- lanes 0..7 of the first 16-lane row of its first register, which spread_rows() has just made
+    // available to both rows: the update takes them as DPP operands (no separate load, no LDS staging)
+    T Xres = T(0);
+    if constexpr (DPPJ) {
+        Xres = Jr.X[0];
+        asm("s_nop 1" : "+v"(Xres));    // (a copy, if the allocator makes one here, is two wait states old before any DPP read)
     }
 
     // ================================ predict(s) =======================================
@@ -2484,45 +2516,51 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     int status = 0;
     bool fail = false;
     if (a.do_update) {
-        status = (sR[7] != T(0)) ? DVI_STATUS_NONFINITE : 0;
+        constexpr bool DPPU = LPI == 32;
+        if constexpr (DPPU) status = (dpp_bcast<7>(Xres) != T(0)) ? DVI_STATUS_NONFINITE : 0;
+        else status = (sR[7] != T(0)) ? DVI_STATUS_NONFINITE : 0;
         T E[7];                             // error estimate at the measured components (group-uniform)
+        if constexpr (!DPPU) {
 #pragma unroll
-        for (int m = 0; m < 7; ++m) E[m] = T(0);
+            for (int m = 0; m < 7; ++m) E[m] = T(0);
+        }
         int napplied = 0;
+        unsigned long long okm[7] = {0, 0, 0, 0, 0, 0, 0};  // (DPPU) lanes whose instance has applied measurement m
         // 32 lanes per instance: the column every lane needs is handed around as DPP operands
         // (no LDS read-back, no barrier); the LDS copy is only written, for the take-back below
-        constexpr bool DPPU = LPI == 32;
+        constexpr int CS = DPPU ? 32 : 24;  // stride of the published columns (DPPU: every lane writes, no predicate)
         if constexpr (DPPU) {
             static_for<0, 7>([&](auto M) {
                 constexpr int m = decltype(M)::value;
                 constexpr int sm = sel[m];
                 const T pm = p[sm];
-                if (active) lds_store1(sB + m * 24 + row, pm);
+                lds_store1(sB + m * CS + lig, pm);
                 T X, Y;                     // column sel_m of the current P: X rows 0..15, Y rows 16..23
                 spread_rows(pm, X, Y);
                 const T csel = dpp_bcast<(sm & 15)>(sm < 16 ? X : Y);
                 const T sv = csel + (PIN ? sN[13 + m] : prm.r[m]);
                 fail = fail || !(sv != T(0) && t_finite(sv));
+                okm[m] = __builtin_amdgcn_ballot_w64(!fail);    // (a scalar copy of the branch mask: the take-back reads it)
                 if (!fail) {
                     const T g = fast_rcp(sv);
-                    const T tau = (sR[m] - E[m]) * g;
-                    const T kk = pm * g;    // gain of this measurement, component `row`
-                    const T nkk = -kk;
-                    e += pm * tau;
+                    const T rm = dpp_bcast<m>(Xres);
+                    const T tau = (m == 0) ? rm * g : (rm - E[m]) * g;      // (E starts at zero: nothing to subtract yet)
+                    const T nkk = pm * -g;  // minus the gain of this measurement, component `row`
+                    if constexpr (m == 0) e = pm * tau;
+                    else e += pm * tau;
                     static_for<m + 1, 7>([&](auto M2) {
                         constexpr int s2 = sel[decltype(M2)::value];
-                        dpp_fmac<(s2 & 15), decltype(M2)::value == m + 1>(E[decltype(M2)::value], s2 < 16 ? X : Y, tau);
+                        dpp_fmac<(s2 & 15), m == 0>(E[decltype(M2)::value], s2 < 16 ? X : Y, tau);
                     });
                     // Joseph form with the optimal gain, Filter.py:383-384: p[j] -= kk * P[j][sel_m]
                     static_for<12, 24>([&](auto J) {
                         constexpr int j = decltype(J)::value;
-                        dpp_fmac<(j & 15), j == 12>(p[j], j < 16 ? X : Y, nkk);
+                        dpp_fmac<(j & 15)>(p[j], j < 16 ? X : Y, nkk);
                     });
                     static_for<0, 12>([&](auto J) {
                         constexpr int j = decltype(J)::value;
                         dpp_fmac<(j & 15)>(p[j], X, nkk);
                     });
-                    napplied = m + 1;
                 }
                 pin_row(p);
                 asm volatile("" : "+v"(e), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
@@ -2568,10 +2606,14 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             // take the applied measurements back, last first (the predicted covariance is restored
             // to rounding; bit-exact when the first pivot fails, e.g. P = 0 and R = 0)
             status |= DVI_STATUS_SINGULAR;
+            if constexpr (DPPU) {           // (how many this lane's instance applied: from the scalar masks of the loop above)
+#pragma unroll
+                for (int m = 0; m < 7; ++m) napplied += (int)((okm[m] >> lane) & 1ull);
+            }
 #pragma unroll
             for (int m = 6; m >= 0; --m) {
                 if (m < napplied) {
-                    const T* cb = sB + m * 24;
+                    const T* cb = sB + m * CS;
                     const T g = fast_rcp(cb[sel[m]] + (PIN ? sN[13 + m] : prm.r[m]));
                     const T kk = cb[row] * g;
 #pragma unroll

@@ -9,7 +9,7 @@ start = next(i for i, l in enumerate(txt) if l.startswith("_Z") and key in l.spl
 c = collections.Counter()
 for l in txt[start + 1:]:
     s = l.strip()
-    if s.startswith("s_endpgm"):
+    if s.startswith(".Lfunc_end"):
         break
     if not s or s[0] in ".;/" or s.split(";")[0].rstrip().endswith(":"):
         continue
