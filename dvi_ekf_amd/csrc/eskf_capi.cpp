@@ -26,6 +26,7 @@ struct dvi_eskf {
     void* d_x;   // [36][B]  state record, structure-of-arrays
     // workspace of the step pipeline (pre -> cov -> post kernels)
     void* d_J;          // [jcap][B][JAC_WORDS]
+    void* d_aux;        // [AUX_WORDS0 + AUX_WORDSK jcap][B] hand-over of the epoch's recurrences to its Jacobian kernel
     int jcap;           // predicts per launch the Jacobian workspace can hold
     void* d_e;          // [B][24]
     int32_t* d_status;  // [B]
@@ -47,6 +48,8 @@ void free_buffers(dvi_eskf* h) {
     if (h->d_P) (void)hipFree(h->d_P);
     if (h->d_x) (void)hipFree(h->d_x);
     if (h->d_J) (void)hipFree(h->d_J);
+    if (h->d_aux) (void)hipFree(h->d_aux);
+    h->d_aux = nullptr;
     if (h->d_e) (void)hipFree(h->d_e);
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_noise) (void)hipFree(h->d_noise);
@@ -62,8 +65,10 @@ bool alloc_buffers(dvi_eskf* h) {
     const size_t B = (size_t)h->B;
     h->d_P = h->d_x = h->d_J = h->d_e = nullptr;
     h->d_status = nullptr;
+    h->d_aux = nullptr;
     h->jcap = 0;
-    if (hipMalloc(&h->d_P, B * 300 * es) != hipSuccess || hipMalloc(&h->d_x, B * 36 * es) != hipSuccess ||
+    if (hipMalloc(&h->d_aux, B * (eskf::AUX_WORDS0 + eskf::AUX_WORDSK) * es) != hipSuccess ||
+        hipMalloc(&h->d_P, B * 300 * es) != hipSuccess || hipMalloc(&h->d_x, B * 36 * es) != hipSuccess ||
         hipMalloc(&h->d_J, B * eskf::JAC_WORDS * es) != hipSuccess ||
         hipMalloc(&h->d_e, B * 24 * es) != hipSuccess ||
         hipMalloc((void**)&h->d_status, B * sizeof(int32_t)) != hipSuccess) {
@@ -93,13 +98,21 @@ int ensure_jcap(dvi_eskf* h, int n_pred, hipStream_t stream) {
     if (n_pred <= h->jcap) return DVI_ESKF_OK;
     if (h->captured || stream_is_capturing(stream)) return DVI_ESKF_ECAPTURE;
     void* nj = nullptr;
+    void* na = nullptr;
     if (hipMalloc(&nj, (size_t)n_pred * (size_t)h->B * eskf::JAC_WORDS * elem_size(h->dtype)) != hipSuccess) return DVI_ESKF_ENOMEM;
+    if (hipMalloc(&na, (size_t)(eskf::AUX_WORDS0 + eskf::AUX_WORDSK * n_pred) * (size_t)h->B * elem_size(h->dtype)) != hipSuccess) {
+        (void)hipFree(nj);
+        return DVI_ESKF_ENOMEM;
+    }
     if (hipDeviceSynchronize() != hipSuccess) {   // earlier launches may still read the old workspace
         (void)hipFree(nj);
+        (void)hipFree(na);
         return DVI_ESKF_EHIP;
     }
     (void)hipFree(h->d_J);
+    (void)hipFree(h->d_aux);
     h->d_J = nj;
+    h->d_aux = na;
     h->jcap = n_pred;
     h->jac_ip = -1;
     return DVI_ESKF_OK;
@@ -123,7 +136,7 @@ eskf::StepArgs base_args(const dvi_eskf* h) {
     std::memset(&a, 0, sizeof a);
     a.P = h->d_P; a.xs = h->d_x;
     a.P_src = h->d_P; a.xs_src = h->d_x;
-    a.J = h->d_J; a.e = h->d_e; a.status_ws = h->d_status; a.noise = h->d_noise;
+    a.J = h->d_J; a.aux = h->d_aux; a.e = h->d_e; a.status_ws = h->d_status; a.noise = h->d_noise;
     a.B = h->B;
     a.rounds = 1;
     return a;

@@ -12,6 +12,7 @@ constexpr int DVI_STATUS_SINGULAR = 1;
 constexpr int DVI_STATUS_NONFINITE = 2;
 constexpr int DVI_STATUS_PENDING = 1 << 30;   // workspace word only: the update's error state is not injected yet
 constexpr int JAC_WORDS = 96;  // words per Jacobian record (eskf_kernels.hip: JW)
+constexpr int AUX_WORDS0 = 12, AUX_WORDSK = 8;   // eskf_kernels.hip: AUX0, AUXK
 constexpr int NOISE_WORDS = 24; // per-instance noise record: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad   // words per Jacobian record (eskf_kernels.hip: JW)
 
 // constants of one filter configuration, in the kernel's working precision; passed by value
@@ -69,6 +70,7 @@ struct StepArgs {
     // workspace owned by the handle
     void* J;            // [n_pred][B][96] records written by the pre kernel: residual of the update (7 + non-finite flag;
                         // first predict's record) | Jacobian blocks
+    void* aux;          // [12 + 8 n_pred][B] what eskf_nominal_kernel hands to eskf_jac_kernel (epochs)
     void* e;            // [B][24] error state of the update
     int32_t* status_ws; // [B]
     int64_t B;

@@ -755,6 +755,130 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
     if (was_pending) a.status_ws[bo] = pend_status & ~DVI_STATUS_PENDING;                  // the injection is done (or dropped)
 }
 
+// ---- the Jacobian blocks of one predict (Filter.py:249-342), in three groups that only share
+// their inputs -- evaluated, as the reference does, at the post-predict dofs / notch with the pre-predict buffers
+// om_old, acc_old, R_WB_old (Filter.py:220-221,325-327).  eskf_pre4_kernel gives the groups to different wavefronts,
+// eskf_jac_kernel to the two halves of a block.
+// (a) what only needs the buffers: A = -dt R_o [a_o]x, Theta = Rm(Om_old)^T, dt; returns R_o
+template <typename T>
+__device__ __forceinline__ void jac_blocks_old_buffers(const T* qo, const T* acc_o, const T* om_o, T dt, Jac<T>& J, T* Ro) {
+    quat_to_mat(qo, Ro);
+    J.dt = dt;
+    T w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) w[i] = -dt * acc_o[i];
+    mat3_skew(Ro, w, J.A);                                                  // -dt R_o [a_o]x
+    T Om[4] = {T(0.5) * dt * om_o[0], T(0.5) * dt * om_o[1], T(0.5) * dt * om_o[2], T(1)};
+    T OmR[9];
+    quat_to_mat(Om, OmR);                                                   // Filter.py:132-134
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) J.Th[3 * i + j] = OmR[3 * j + i];
+}
+// (b) the delta-p_C rows: Bm, Cm (and the first half of N6) from p_CB and its derivatives
+template <typename T>
+__device__ __forceinline__ void jac_blocks_position(const DevParams<T>& prm, const ProbeTrig<T>& t, const T* dofs, const T* om_t,
+                                                    const T* Ro, T dt, Jac<T>& J) {
+    T z6[3], z6_1[3], z6_2[3], e5[3], e6[3], e5_1[3], e5_2[3], e6_1[3], e6_2[3];
+    z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
+    z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
+    z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
+    E5(t.s3, t.c3, e5);     E6(t.s3, t.c3, e6);
+    E5_1(t.s3, t.c3, e5_1); E6_1(t.s3, t.c3, e6_1);
+    E5_2(t.s3, t.c3, e5_2); E6_2(t.s3, t.c3, e6_2);
+    const T lq = prm.L - dofs[3], q5 = dofs[4], q6 = dofs[5];
+    T p[3], Jp[18];   // Jp[3][6]: d p_CB / d q1..q6 (the q7 column is identically zero)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        p[i] = lq * z6[i] + q5 * e5[i] + q6 * e6[i];
+        Jp[6 * i + 0] = lq * z6_1[i] + q5 * e5_1[i] + q6 * e6_1[i];
+        Jp[6 * i + 1] = lq * z6_2[i] + q5 * e5_2[i] + q6 * e6_2[i];
+        Jp[6 * i + 2] = q5 * e6[i] - q6 * e5[i];
+        Jp[6 * i + 3] = -z6[i];
+        Jp[6 * i + 4] = e5[i];
+        Jp[6 * i + 5] = e6[i];
+    }
+    // noise symbols are evaluated at their std-devs (Filter.py:330-333); "true" v_CB := p_CB (Probe.py:458)
+    T wv[3], cr[3];
+    cross3(om_t, p, cr);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wv[i] = -dt * (p[i] + cr[i]);
+    mat3_skew(Ro, wv, J.Bm);                                                // -dt R_o [p + om_t x p]x
+    T RoS[9], M[9];                                                         // M = dt R_o (I + [om_t]x);  Cm = M Jp
+    mat3_skew(Ro, om_t, RoS);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) M[i] = dt * (Ro[i] + RoS[i]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            J.Cm[6 * r + c] = M[3 * r] * Jp[c] + M[3 * r + 1] * Jp[6 + c] + M[3 * r + 2] * Jp[12 + c];
+    if (prm.jfull) {    // noise Jacobian, camera position rows: dt R_o [p]x
+        T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
+        mat3_skew(Ro, dp, J.N6);
+    }
+}
+// (c) the delta-theta_C rows: Dm, Em (and the second half of N6) from R_BC and its derivatives
+template <typename T>
+__device__ __forceinline__ void jac_blocks_attitude(const DevParams<T>& prm, const ProbeTrig<T>& t, T thd, const T* om_t, const T* om_o,
+                                                    T dt, Jac<T>& J) {
+    const T st = prm.st, ct = prm.ct;
+    T z6[3], z6_1[3], z6_2[3], aa[3], g[3], a_1[3], a_2[3], g_1[3], g_2[3];
+    z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
+    z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
+    z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
+    E5(t.sp, t.cp, aa);     E6(t.sp, t.cp, g);
+    E5_1(t.sp, t.cp, a_1);  E6_1(t.sp, t.cp, g_1);
+    E5_2(t.sp, t.cp, a_2);  E6_2(t.sp, t.cp, g_2);
+    T RBC[9], u_t[3], u_o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        RBC[3 * i + 0] = -aa[i];
+        RBC[3 * i + 1] = ct * g[i] + st * z6[i];
+        RBC[3 * i + 2] = -st * g[i] + ct * z6[i];
+        u_t[i] = om_t[i] + z6[i] * thd;
+        u_o[i] = om_o[i] + z6[i] * thd;
+    }
+    // delta-theta_C rows: d/dq_i [ R_BC^T (om_t + z6 thd) ] with only R_BC and z6 depending on q
+    // columns of dR_BC/dq_i are (-da, ct dg + st dz, -st dg + ct dz)
+    auto dcol = [&](const T* da, const T* dg, const T* dz, const T* dzr, int col) {
+        T d0 = T(0), d1 = T(0), d2 = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            d0 += -da[k] * u_t[k];
+            d1 += (ct * dg[k] + st * dz[k]) * u_t[k];
+            d2 += (-st * dg[k] + ct * dz[k]) * u_t[k];
+        }
+        T rz[3];
+        mat3T_vec(RBC, dzr, rz);
+        J.Dm[0 * 4 + col] = dt * (d0 + rz[0] * thd);
+        J.Dm[1 * 4 + col] = dt * (d1 + rz[1] * thd);
+        J.Dm[2 * 4 + col] = dt * (d2 + rz[2] * thd);
+    };
+    const T zero3[3] = {T(0), T(0), T(0)};
+    T ma[3] = {-aa[0], -aa[1], -aa[2]}, mg[3] = {-g[0], -g[1], -g[2]};
+    dcol(a_1, g_1, z6_1, z6_1, 0);      // q1
+    dcol(a_2, g_2, z6_2, z6_2, 1);      // q2
+    dcol(g, ma, zero3, zero3, 2);       // q3:  da/dphi = g, dg/dphi = -a
+    dcol(mg, aa, zero3, zero3, 3);      // q7:  phi = q3 - q7
+    T ac[3], bc[3], hs[3];
+    mat3T_vec(RBC, u_t, ac);
+    mat3T_vec(RBC, u_o, bc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hs[i] = T(0.5) * dt * (ac[i] + bc[i]);
+    // Em = I - [hs]x
+    J.Em[0] = T(1);   J.Em[1] = hs[2];  J.Em[2] = -hs[1];
+    J.Em[3] = -hs[2]; J.Em[4] = T(1);   J.Em[5] = hs[0];
+    J.Em[6] = hs[1];  J.Em[7] = -hs[0]; J.Em[8] = T(1);
+    if (prm.jfull) {    // noise Jacobian, camera attitude rows: -dt R_BC^T
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // eskf_pre4_kernel: the pre kernel of a launch with exactly ONE predict (the pair step, a single predict),
 // re-cut into four short chains.  Four wavefronts share 64 instances (lane = instance); what one chain needs from
@@ -1063,19 +1187,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
             t_sincos(q2n, s2, c2);
             xw[0] = s1; xw[1] = c1; xw[2] = s2; xw[3] = c2;
             row[J_RES + 7] = T(0);                      // (the residual's flag word: raised by W0 / W1 after barrier 1b)
-            quat_to_mat(qo, Ro);
-            J.dt = dt;
-            T w[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) w[i] = -dt * acc_o[i];
-            mat3_skew(Ro, w, J.A);                                                  // -dt R_o [a_o]x
-            T Om[4] = {T(0.5) * dt * om_o[0], T(0.5) * dt * om_o[1], T(0.5) * dt * om_o[2], T(1)};
-            T OmR[9];
-            quat_to_mat(Om, OmR);                                                   // Filter.py:132-134
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) J.Th[3 * i + j] = OmR[3 * j + i];
+            jac_blocks_old_buffers(qo, acc_o, om_o, dt, J, Ro);
         } else {
             T s3, c3, sp, cp, spn, cpn;
             t_sincos(q3n, s3, c3);
@@ -1104,99 +1216,9 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #pragma unroll
                 for (int i = 0; i < 6; ++i) xo[(10 + i) * B + b] = dofs[i];
             }
-            T z6[3], z6_1[3], z6_2[3], e5[3], e6[3], e5_1[3], e5_2[3], e6_1[3], e6_2[3];
-            z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
-            z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
-            z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
-            E5(t.s3, t.c3, e5);     E6(t.s3, t.c3, e6);
-            E5_1(t.s3, t.c3, e5_1); E6_1(t.s3, t.c3, e6_1);
-            E5_2(t.s3, t.c3, e5_2); E6_2(t.s3, t.c3, e6_2);
-            const T lq = prm.L - dofs[3], q5 = dofs[4], q6 = dofs[5];
-            T p[3], Jp[18];   // Jp[3][6]: d p_CB / d q1..q6 (the q7 column is identically zero)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                p[i] = lq * z6[i] + q5 * e5[i] + q6 * e6[i];
-                Jp[6 * i + 0] = lq * z6_1[i] + q5 * e5_1[i] + q6 * e6_1[i];
-                Jp[6 * i + 1] = lq * z6_2[i] + q5 * e5_2[i] + q6 * e6_2[i];
-                Jp[6 * i + 2] = q5 * e6[i] - q6 * e5[i];
-                Jp[6 * i + 3] = -z6[i];
-                Jp[6 * i + 4] = e5[i];
-                Jp[6 * i + 5] = e6[i];
-            }
-            // noise symbols are evaluated at their std-devs (Filter.py:330-333); "true" v_CB := p_CB (Probe.py:458)
-            T wv[3], cr[3];
-            cross3(om_t, p, cr);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) wv[i] = -dt * (p[i] + cr[i]);
-            mat3_skew(Ro, wv, J.Bm);                                                // -dt R_o [p + om_t x p]x
-            T RoS[9], M[9];                                                         // M = dt R_o (I + [om_t]x);  Cm = M Jp
-            mat3_skew(Ro, om_t, RoS);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) M[i] = dt * (Ro[i] + RoS[i]);
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    J.Cm[6 * r + c] = M[3 * r] * Jp[c] + M[3 * r + 1] * Jp[6 + c] + M[3 * r + 2] * Jp[12 + c];
-            if (prm.jfull) {    // noise Jacobian, camera position rows: dt R_o [p]x
-                T dp[3] = {dt * p[0], dt * p[1], dt * p[2]};
-                mat3_skew(Ro, dp, J.N6);
-            }
+            jac_blocks_position(prm, t, dofs, om_t, Ro, dt, J);
         } else {
-            const T st = prm.st, ct = prm.ct;
-            T z6[3], z6_1[3], z6_2[3], aa[3], g[3], a_1[3], a_2[3], g_1[3], g_2[3];
-            z6[0] = -t.s1 * t.c2;   z6[1] = -t.c1 * t.c2;  z6[2] = t.s2;
-            z6_1[0] = -t.c1 * t.c2; z6_1[1] = t.s1 * t.c2; z6_1[2] = T(0);
-            z6_2[0] = t.s1 * t.s2;  z6_2[1] = t.c1 * t.s2; z6_2[2] = t.c2;
-            E5(t.sp, t.cp, aa);     E6(t.sp, t.cp, g);
-            E5_1(t.sp, t.cp, a_1);  E6_1(t.sp, t.cp, g_1);
-            E5_2(t.sp, t.cp, a_2);  E6_2(t.sp, t.cp, g_2);
-            T RBC[9], u_t[3], u_o[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                RBC[3 * i + 0] = -aa[i];
-                RBC[3 * i + 1] = ct * g[i] + st * z6[i];
-                RBC[3 * i + 2] = -st * g[i] + ct * z6[i];
-                u_t[i] = om_t[i] + z6[i] * thd;
-                u_o[i] = om_o[i] + z6[i] * thd;
-            }
-            // delta-theta_C rows: d/dq_i [ R_BC^T (om_t + z6 thd) ] with only R_BC and z6 depending on q
-            // columns of dR_BC/dq_i are (-da, ct dg + st dz, -st dg + ct dz)
-            auto dcol = [&](const T* da, const T* dg, const T* dz, const T* dzr, int col) {
-                T d0 = T(0), d1 = T(0), d2 = T(0);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    d0 += -da[k] * u_t[k];
-                    d1 += (ct * dg[k] + st * dz[k]) * u_t[k];
-                    d2 += (-st * dg[k] + ct * dz[k]) * u_t[k];
-                }
-                T rz[3];
-                mat3T_vec(RBC, dzr, rz);
-                J.Dm[0 * 4 + col] = dt * (d0 + rz[0] * thd);
-                J.Dm[1 * 4 + col] = dt * (d1 + rz[1] * thd);
-                J.Dm[2 * 4 + col] = dt * (d2 + rz[2] * thd);
-            };
-            const T zero3[3] = {T(0), T(0), T(0)};
-            T ma[3] = {-aa[0], -aa[1], -aa[2]}, mg[3] = {-g[0], -g[1], -g[2]};
-            dcol(a_1, g_1, z6_1, z6_1, 0);      // q1
-            dcol(a_2, g_2, z6_2, z6_2, 1);      // q2
-            dcol(g, ma, zero3, zero3, 2);       // q3:  da/dphi = g, dg/dphi = -a
-            dcol(mg, aa, zero3, zero3, 3);      // q7:  phi = q3 - q7
-            T ac[3], bc[3], hs[3];
-            mat3T_vec(RBC, u_t, ac);
-            mat3T_vec(RBC, u_o, bc);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) hs[i] = T(0.5) * dt * (ac[i] + bc[i]);
-            // Em = I - [hs]x
-            J.Em[0] = T(1);   J.Em[1] = hs[2];  J.Em[2] = -hs[1];
-            J.Em[3] = -hs[2]; J.Em[4] = T(1);   J.Em[5] = hs[0];
-            J.Em[6] = hs[1];  J.Em[7] = -hs[0]; J.Em[8] = T(1);
-            if (prm.jfull) {    // noise Jacobian, camera attitude rows: -dt R_BC^T
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) J.N6[9 + 3 * i + j] = -dt * RBC[3 * j + i];
-            }
+            jac_blocks_attitude(prm, t, thd, om_t, om_o, dt, J);
         }
     }
     if (role == 0) ESKF_STAMP(4)
@@ -1219,6 +1241,345 @@ template <typename T>
 __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams<T> prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     pre4_body<T>(a, prm, smem_raw, (int)blockIdx.x);
+}
+
+// ----------------------------------------------------------------------------------
+// Epochs (launches with n >= 2 predicts: Filter.run_one_epoch / propagate_imu, Filter.py:170-217): the pre work of a
+// launch as two kernels.
+//
+//   eskf_nominal_kernel   lane per instance, serial over the predicts -- but only what IS a recurrence: wavefront 0
+//                         carries attitude, position and velocity (q -> R -> R+ -> Markley, ~150 operations per
+//                         predict), wavefront 1 the camera attitude and the notch states (and forms the residual at
+//                         the end).  p_CB does not depend on the notch angle, so it is a constant of the epoch; the
+//                         sines / cosines of q1..q3 are evaluated once, phi = q3 - q7 only when the notch moves.  Per
+//                         predict the kernel leaves behind what that predict's Jacobian blocks need and only a
+//                         recurrence can know: q_old(k), the post-predict notch angle and rate, sin / cos of the
+//                         post-predict phi (8 words in `aux`, lane-contiguous).
+//   eskf_jac_kernel       lane per (predict, instance): the Jacobian blocks of all n predicts of all instances at
+//                         once -- they depend on q_old(k), the notch state after predict k, om(k-1), acc(k-1), dt(k) and
+//                         the extrinsics of the epoch, not on each other -- with no transcendental left in it.
+//
+// The two-role eskf_pre_kernel ran the blocks of the n predicts one after the other in ONE wavefront per 64 instances
+// next to a 900-operation nominal chain (config #5, 33 predicts, B = 8 192: 118 us for 79 us of covariance kernel; 128
+// wavefronts on a chip that holds 4 096).
+// aux layout, word w of instance b at aux[w * B + b]:   0..2 om_old(0) | 3..5 acc_old(0) | 6..11 s1 c1 s2 c2 s3 c3 at
+// the post-predict dofs | then per predict k, 8 words from 12 + 8 k: q_old(k) 4 | notch+ 2 (angle, rate) | sin, cos phi+
+// ----------------------------------------------------------------------------------
+constexpr int AUX0 = 12, AUXK = 8;
+template <typename T, bool SIMU>
+__global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevParams<T> prm) {
+    __shared__ T sX[9 * 64];                            // s1 c1 s2 c2 s3 c3 (pre-predict dofs) | p_cam after the last predict
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;                 // wave-uniform
+    const int64_t b_raw = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = b_raw < a.B;
+    const int64_t b = live ? b_raw : a.B - 1;          // tail lanes recompute the last instance, write nothing
+    const T* xi = reinterpret_cast<const T*>(a.xs_src);
+    T* xo = reinterpret_cast<T*>(a.xs);
+    T* aux = reinterpret_cast<T*>(a.aux);
+    const int64_t B = a.B;
+    const int n = a.n_pred;
+    auto X = [&](int w) { return xi[(int64_t)w * B + b]; };
+    int pend_status = 0;
+    if (a.pending_hint) pend_status = a.status_ws[b];
+    const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
+    const bool inject_now = was_pending && !a.drop_pending && !(pend_status & DVI_STATUS_SINGULAR);
+    bool zeroed[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) zeroed[i] = !prm.hold_frozen && ((prm.frozen_mask >> i) & 1);   // Filter.py:243-245
+
+    if (role == 0) {
+        // ---- position, velocity, attitude ---------------------------------------------------------------
+        T p[3], v[3], q[4], pc[3], om_o[3], acc_o[3], qo[4], dofs[6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { p[i] = X(i); v[i] = X(3 + i); pc[i] = X(19 + i); om_o[i] = X(26 + i); acc_o[i] = X(29 + i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { q[i] = X(6 + i); qo[i] = X(32 + i); }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dofs[i] = X(10 + i);
+        T e15[15], e1821[3];
+        if (a.pending_hint) { load_epend(a, b, 0, 15, e15); load_epend(a, b, 18, 3, e1821); }
+        T dt, om_n[3], acc_n[3];
+        load_imu_sample(a, 0, b, dt, om_n, acc_n);
+        if (inject_now) {                               // state.py:46-60,105-129
+            T th[3] = {e15[6], e15[7], e15[8]}, dq[4], qn[4];
+            quat_about_axis(norm3(th), th, dq);
+            quat_mul(q, dq, qn);
+            quat_nrm(qn);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { p[i] += e15[i]; v[i] += e15[3 + i]; pc[i] += e1821[i]; }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dofs[i] += e15[9 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q[i] = qn[i];
+        }
+        // probe: p_CB at the dofs the first predict sees and -- frozen DOFs are zeroed by it -- at the ones every later
+        // predict (and every Jacobian block) sees; the trigonometry of the latter goes to the Jacobian kernel
+        ProbeTrig<T> t0, t1;
+        t_sincos(dofs[0], t0.s1, t0.c1);
+        t_sincos(dofs[1], t0.s2, t0.c2);
+        t_sincos(dofs[2], t0.s3, t0.c3);
+        t0.sp = t0.cp = T(0);
+        t1 = t0;
+        if (zeroed[0]) { t1.s1 = T(0); t1.c1 = T(1); }
+        if (zeroed[1]) { t1.s2 = T(0); t1.c2 = T(1); }
+        if (zeroed[2]) { t1.s3 = T(0); t1.c3 = T(1); }
+        sX[0 * 64 + lane] = t0.s1; sX[1 * 64 + lane] = t0.c1; sX[2 * 64 + lane] = t0.s2; sX[3 * 64 + lane] = t0.c2;
+        sX[4 * 64 + lane] = t0.s3; sX[5 * 64 + lane] = t0.c3;
+        auto probe_p = [&](const ProbeTrig<T>& t, const T* d, T* pB) {
+            T z6[3], e5[3], e6[3];
+            z6[0] = -t.s1 * t.c2; z6[1] = -t.c1 * t.c2; z6[2] = t.s2;
+            E5(t.s3, t.c3, e5); E6(t.s3, t.c3, e6);
+            const T lq = prm.L - d[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) pB[i] = lq * z6[i] + d[4] * e5[i] + d[5] * e6[i];
+        };
+        T pB0[3], pB1[3];
+        probe_p(t0, dofs, pB0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (zeroed[i]) dofs[i] = T(0);
+        probe_p(t1, dofs, pB1);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { aux[(0 + i) * B + b] = om_o[i]; aux[(3 + i) * B + b] = acc_o[i]; }
+            aux[6 * B + b] = t1.s1; aux[7 * B + b] = t1.c1; aux[8 * B + b] = t1.s2; aux[9 * B + b] = t1.c2;
+            aux[10 * B + b] = t1.s3; aux[11 * B + b] = t1.c3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aux[(AUX0 + i) * B + b] = qo[i];       // q_old of the first predict: the stale buffer (Filter.py:227)
+        }
+        __syncthreads();                                // A: trigonometry published, old state read by both wavefronts
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xo[(10 + i) * B + b] = dofs[i];
+        }
+        for (int k = 0; k < n; ++k) {
+            T dt2, om2[3], acc2[3];                     // the next sample is on its way while this predict is computed
+            load_imu_sample<T, SIMU>(a, k + 1, b, dt2, om2, acc2);
+            T R[9], om_avg[3], w[3], RS[9], Rn[9], a1[3], a2[3], acc_avg[3], cr[3], Rcr[3];
+            quat_to_mat(q, R);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { om_avg[i] = (om_o[i] + om_n[i]) * T(0.5); w[i] = dt * om_avg[i]; }
+            mat3_skew(R, w, RS);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Rn[i] = R[i] + RS[i];                       // equations.py:46
+            mat3_vec(R, acc_o, a1);
+            mat3_vec(Rn, acc_n, a2);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);      // equations.py:47
+            cross3(om_avg, k == 0 ? pB0 : pB1, cr);                                 // BB_v_CB == 0
+            mat3_vec(R, cr, Rcr);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const T vi = v[i];
+                p[i] = p[i] + dt * vi + (dt * dt * T(0.5)) * acc_avg[i];            // equations.py:76
+                v[i] = vi + dt * acc_avg[i];                                        // equations.py:77
+                pc[i] = pc[i] + dt * vi + dt * Rcr[i];                              // equations.py:83-85
+                om_o[i] = om_n[i]; acc_o[i] = acc_n[i];                             // Filter.py:225-226
+            }
+            mat_to_quat(Rn, q);                                                     // state.py:67
+            if (k + 1 < n && live) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) aux[(AUX0 + AUXK * (k + 1) + i) * B + b] = q[i];   // = R_WB_old of predict k + 1 (Filter.py:227)
+            }
+            dt = dt2;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { om_n[i] = om2[i]; acc_n[i] = acc2[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sX[(6 + i) * 64 + lane] = pc[i];
+        __syncthreads();                                // B: p_cam for the residual
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                xo[(0 + i) * B + b] = p[i]; xo[(3 + i) * B + b] = v[i]; xo[(19 + i) * B + b] = pc[i];
+                xo[(26 + i) * B + b] = om_o[i]; xo[(29 + i) * B + b] = acc_o[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xo[(6 + i) * B + b] = q[i]; xo[(32 + i) * B + b] = q[i]; }
+        }
+        return;
+    }
+    // ---- camera attitude, notch states, residual ---------------------------------------------------------
+    T qc[4], notch[3], om_o[3], q3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { notch[i] = X(16 + i); om_o[i] = X(26 + i); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qc[i] = X(22 + i);
+    q3 = X(12);
+    T e69[3], e11 = T(0), e1518[3], e2124[3];
+    if (a.pending_hint) {
+        load_epend(a, b, 6, 3, e69); load_epend(a, b, 11, 1, &e11); load_epend(a, b, 15, 3, e1518); load_epend(a, b, 21, 3, e2124);
+    }
+    T gpos[3] = {T(0), T(0), T(0)}, qraw[4] = {T(0), T(0), T(0), T(1)}, ang_notch = T(0);
+    if (a.do_update) {
+        const int64_t mo = a.meas_stride ? b : 0;
+        const T* gp = reinterpret_cast<const T*>(a.pos) + mo * 3;
+        const T* gq = reinterpret_cast<const T*>(a.quat) + mo * 4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gpos[i] = gp[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qraw[i] = gq[i];
+        ang_notch = reinterpret_cast<const T*>(a.notch)[mo];
+    }
+    T dt, om_n[3], acc_n[3];
+    load_imu_sample(a, 0, b, dt, om_n, acc_n);
+    if (inject_now) {
+        T dqc[4], qcn[4];
+        quat_about_axis(norm3(e2124), e69, dqc);   // sic (state.py:124)
+        quat_mul(qc, dqc, qcn);
+        quat_nrm(qcn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qc[i] = qcn[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) notch[i] += e1518[i];
+        q3 += e11;
+    }
+    T qm[4] = {T(0), T(0), T(0), T(1)};
+    if (a.do_update) {                                                              // Filter.py:364-365
+        T nq[4] = {T(0), T(0), T(0), T(1)};
+        t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
+        quat_mul(nq, qraw, qm);
+        quat_nrm(qm);
+        qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
+    }
+    __syncthreads();                                    // A
+    T s1 = sX[0 * 64 + lane], c1 = sX[1 * 64 + lane], s2 = sX[2 * 64 + lane], c2 = sX[3 * 64 + lane];
+    T ph_arg = T(NAN), sp = T(0), cp = T(1);            // sin / cos of the phi they were last evaluated at
+    for (int k = 0; k < n; ++k) {
+        T dt2, om2[3], acc2[3];
+        load_imu_sample<T, SIMU>(a, k + 1, b, dt2, om2, acc2);
+        if (k == 1) {                                   // (from the second predict on the frozen DOFs are zero)
+            if (zeroed[0]) { s1 = T(0); c1 = T(1); }
+            if (zeroed[1]) { s2 = T(0); c2 = T(1); }
+            if (zeroed[2]) q3 = T(0);
+        }
+        const T phi = q3 - notch[0];
+        if (!(phi == ph_arg)) { ph_arg = phi; t_sincos(phi, sp, cp); }
+        ProbeTrig<T> t;
+        t.s1 = s1; t.c1 = c1; t.s2 = s2; t.c2 = c2; t.s3 = t.c3 = T(0); t.sp = sp; t.cp = cp;
+        T RBC[9], z6[3];
+        {
+            T aa[3], g[3];
+            z6[0] = -t.s1 * t.c2; z6[1] = -t.c1 * t.c2; z6[2] = t.s2;
+            E5(t.sp, t.cp, aa); E6(t.sp, t.cp, g);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                RBC[3 * i + 0] = -aa[i];
+                RBC[3 * i + 1] = prm.ct * g[i] + prm.st * z6[i];
+                RBC[3 * i + 2] = -prm.st * g[i] + prm.ct * z6[i];
+            }
+        }
+        T u[3], C_om[3], wc[3], Rc[9], RcS[9], Rcn[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = om_o[i] + z6[i] * notch[1];
+        mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wc[i] = dt * C_om[i];
+        quat_to_mat(qc, Rc);
+        mat3_skew(Rc, wc, RcS);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rcn[i] = Rc[i] + RcS[i];                        // equations.py:86
+        mat_to_quat(Rcn, qc);                                                       // state.py:72
+        notch[0] += dt * notch[1];                                                  // equations.py:80-82
+        notch[1] += dt * notch[2];
+        // what the Jacobian blocks of this predict are evaluated at: the dofs after it (frozen ones zeroed), the notch after it
+        const T phi_n = (zeroed[2] ? T(0) : q3) - notch[0];
+        if (!(phi_n == ph_arg)) { ph_arg = phi_n; t_sincos(phi_n, sp, cp); }
+        if (live) {
+            T* ak = aux + (int64_t)(AUX0 + AUXK * k) * B + b;
+            ak[4 * B] = notch[0]; ak[5 * B] = notch[1]; ak[6 * B] = sp; ak[7 * B] = cp;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { om_o[i] = om_n[i]; om_n[i] = om2[i]; }
+        dt = dt2;
+    }
+    __syncthreads();                                    // B
+    if (!live) return;
+    if (a.do_update) {                                                              // Filter.py:369-375
+        T qe[4];
+        quat_mul(qm, qc, qe);
+        quat_nrm(qe);
+        T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
+        T flag = T(0);
+        if (nv > T(1)) { nv = T(1); flag = T(1); }
+        const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+        const T f = (nv == T(0)) ? T(0) : ang / nv;
+        T r[7];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { r[i] = gpos[i] - sX[(6 + i) * 64 + lane]; r[3 + i] = f * qe[i]; }
+        r[6] = ang_notch - notch[0];
+        // a NaN / inf measurement or state propagates exactly as it does in the reference (NumPy arithmetic, no
+        // check); the instance is flagged, its neighbours are not affected
+        if (!t_finite(r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6])) flag = T(1);
+        T* gr = reinterpret_cast<T*>(a.J) + b * JW + J_RES;      // (record of the launch's first predict)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) gr[i] = r[i];
+        gr[7] = flag;                                         // asin argument was clamped, or non-finite residual
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xo[(16 + i) * B + b] = notch[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xo[(22 + i) * B + b] = qc[i];
+    if (was_pending) a.status_ws[b] = pend_status & ~DVI_STATUS_PENDING;              // the injection is done (or dropped)
+}
+
+template <typename T>
+__global__ __launch_bounds__(128, 4) void eskf_jac_kernel(StepArgs a, DevParams<T> prm) {
+    // 64 (predict, instance) jobs per block, predict-major like the records J[n][B][JW]: wavefront 0 forms A, Theta,
+    // Bm, Cm of its job, wavefront 1 Dm and Em; the block words of the 64 records are staged in LDS (odd row stride)
+    // and written out whole, behind the residual words (which eskf_nominal_kernel writes for the first predict)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* sJ = reinterpret_cast<T*>(smem_raw);
+    const int JS = prm.jfull ? JB_FULL : JB_CORE;
+    const int lane = threadIdx.x & 63;
+    const int role = threadIdx.x >> 6;
+    const int64_t B = a.B;
+    const int64_t njobs = (int64_t)a.n_pred * B;
+    const int64_t job0 = (int64_t)blockIdx.x * 64;
+    const int64_t job_raw = job0 + lane;
+    const int64_t job = job_raw < njobs ? job_raw : njobs - 1;      // tail lanes recompute the last job, write nothing
+    const int k = (int)(job / B);
+    const int64_t b = job - (int64_t)k * B;
+    const T* aux = reinterpret_cast<const T*>(a.aux);
+    const T* ak = aux + (int64_t)(AUX0 + AUXK * k) * B + b;
+    const T dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? (int64_t)k * B + b : k];
+    T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
+    if (a.noise) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sig_om[i] = reinterpret_cast<const T*>(a.noise)[b * NOISE_WORDS + 20 + i];
+    }
+    // the buffers predict k is linearised with: the sample before it (the state's buffers for the first predict)
+    T om_o[3], om_t[3];
+    const int64_t so = a.imu_stride ? ((int64_t)(k - 1) * B + b) * 3 : (int64_t)(k - 1) * 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        om_o[i] = k == 0 ? aux[(0 + i) * B + b] : reinterpret_cast<const T*>(a.om)[so + i];
+        om_t[i] = om_o[i] - sig_om[i];
+    }
+    ProbeTrig<T> t;
+    t.s1 = aux[6 * B + b]; t.c1 = aux[7 * B + b]; t.s2 = aux[8 * B + b]; t.c2 = aux[9 * B + b];
+    t.s3 = aux[10 * B + b]; t.c3 = aux[11 * B + b];
+    t.sp = ak[6 * B]; t.cp = ak[7 * B];
+    Jac<T>& J = *reinterpret_cast<Jac<T>*>(sJ + lane * JS);
+    if (role == 0) {
+        T acc_o[3], qo[4], dofs[6], Ro[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc_o[i] = k == 0 ? aux[(3 + i) * B + b] : reinterpret_cast<const T*>(a.acc)[so + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qo[i] = ak[i * B];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dofs[i] = reinterpret_cast<const T*>(a.xs)[(10 + i) * B + b];   // (post-predict: stored by eskf_nominal_kernel)
+        jac_blocks_old_buffers(qo, acc_o, om_o, dt, J, Ro);
+        jac_blocks_position(prm, t, dofs, om_t, Ro, dt, J);
+    } else {
+        jac_blocks_attitude(prm, t, ak[5 * B], om_t, om_o, dt, J);
+    }
+    __syncthreads();
+    T* gJ = reinterpret_cast<T*>(a.J) + job0 * JW + J_B0;
+    const int nrec = (njobs - job0 < 64) ? (int)(njobs - job0) : 64;
+    const int first = role * 32, last = (first + 32 < nrec) ? first + 32 : nrec;
+    if (prm.jfull) store_records<T, JB_FULL>(sJ, gJ, last, lane, first);
+    else store_records<T, JB_CORE>(sJ, gJ, last, lane, first);
 }
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
@@ -3043,6 +3404,8 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
 // diagnostic switch (environment DVI_ESKF_PRE_LEGACY=1, read once): single-predict launches through the two-role
 // pre kernel instead of eskf_pre4_kernel -- the A/B of the two and the bitwise test of one against the other
 static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEGACY"); return e && e[0] == '1'; }();
+// largest batch whose epochs go through eskf_nominal_kernel + eskf_jac_kernel (DVI_ESKF_EPOCH_SPLIT_MAX; -1 = always)
+static const int64_t g_epoch_split_max = []() { const char* e = getenv("DVI_ESKF_EPOCH_SPLIT_MAX"); return e ? (int64_t)atoll(e) : (int64_t)40960; }();
 
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
@@ -3054,7 +3417,22 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
         hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
     } else if (a.n_pred == 1)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
-    else if (!a.imu_stride && !a.dt_stride)
+    else if (a.n_pred >= 2 && !g_pre_legacy && a.aux && (a.B <= g_epoch_split_max || g_epoch_split_max < 0)) {
+        // epochs: the recurrences, then the Jacobian blocks of all predicts at once.  Pays while the batch under-fills
+        // the chip for a lane-per-instance kernel (measured, epoch time against the two-role kernel below, fp64 / fp32,
+        // 10 and 33 predicts: B = 1 024 x0.50-0.71, 8 192 x0.70-0.81, 16 384 x0.83-0.93, 32 768 x0.97-1.02, 65 536
+        // x1.02-1.05: there 1 024 blocks fill every CU, the serial loop is no longer exposed, and the extra launch and
+        // the hand-over words cost more than they save)
+        const dim3 gb((unsigned)((a.B + 63) / 64));
+        if (!a.imu_stride && !a.dt_stride) hipLaunchKernelGGL((eskf_nominal_kernel<T, true>), gb, dim3(128), 0, stream, a, prm);
+        else hipLaunchKernelGGL((eskf_nominal_kernel<T, false>), gb, dim3(128), 0, stream, a, prm);
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+        const int64_t njobs = (int64_t)a.n_pred * a.B;
+        if ((njobs + 63) / 64 > 0x7fffffffLL) return hipErrorInvalidValue;
+        const size_t jl = (size_t)64 * (prm.jfull ? JB_FULL : JB_CORE) * sizeof(T);
+        hipLaunchKernelGGL((eskf_jac_kernel<T>), dim3((unsigned)((njobs + 63) / 64)), dim3(128), jl, stream, a, prm);
+    } else if (!a.imu_stride && !a.dt_stride)
         hipLaunchKernelGGL((eskf_pre_kernel<T, false, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     else
         hipLaunchKernelGGL((eskf_pre_kernel<T, false>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);

@@ -61,6 +61,24 @@ def main(scenario, out):
     f.predict(0.05, rng.normal(0, 0.5, 3), rng.normal(0, 20.0, 3))   # a lone predict, broadcast sample, injection pending
     for key, v in f.get_state().items():
         res[key] = v.cpu().numpy()
+    # epochs (n predicts + update in one launch): per-instance IMU streams with an injection pending, then a shared stream
+    # with moving notch rates (the trigonometry of phi changes from predict to predict)
+    h = f.clone()
+    n = 5
+    st, _ = h.step(0.05, rng.normal(0, 0.5, 3), rng.normal(0, 20.0, 3), x0[:, 19:22], x0[:, 22:26], x0[:, 16])
+    st, _ = h.epoch(0.02 * rng.uniform(0.5, 1.5, (n, B)), rng.normal(0, 0.5, (n, B, 3)), rng.normal(0, 20.0, (n, B, 3)),
+                    x0[:, 19:22] + 0.2, x0[:, 22:26], x0[:, 16])
+    res["ep_st"] = st.cpu().numpy()
+    for key, v in h.get_state().items():
+        res["ep_" + key] = v.cpu().numpy()
+    if keep:
+        Fx, Fi = h.jacobians()
+        res["ep_Fx"], res["ep_Fi"] = Fx.cpu().numpy(), Fi.cpu().numpy()
+    n = 7
+    st, _ = h.epoch(np.full(n, 0.01), rng.normal(0, 0.5, (n, 3)), rng.normal(0, 20.0, (n, 3)), x0[:, 19:22] + 0.1, x0[:, 22:26], x0[:, 16])
+    res["ep2_st"] = st.cpu().numpy()
+    for key, v in h.get_state().items():
+        res["ep2_" + key] = v.cpu().numpy()
     np.savez(out, **res)
 
 

@@ -7,7 +7,7 @@ perturbations by many orders of magnitude (two fp64 implementations that agree t
 apart at step 10 000), so a free-running comparison of two arithmetics is a statement about the arithmetic only
 up to step ~1 000.  What is asserted (tolerances measured on MI355X):
   * the device IMU stream equals the host restatement (<= 1e-12 relative);
-  * fp64 vs the C oracle, 16 sampled instances, free-running: <= 1e-9 at IMU steps 100 and 1 000;
+  * fp64 vs the C oracle, 64 sampled instances, free-running: <= 1e-9 at IMU steps 100 and 1 000;
     and over the LAST hundred steps 9 900..10 000 with the oracle started from the GPU's state at step 9 900;
   * fp32 vs fp64, all 8192 instances: free-running at steps 100 and 1 000, and over 9 900..10 000 with the fp32
     filter restarted from the fp64 state at step 9 900 (FP32_TOL); the free-running difference at step 10 000 is
@@ -98,8 +98,8 @@ def test_config5_ten_thousand_steps_fp64_vs_oracle_and_fp32_vs_fp64():
     g32.set_state(x=s["x"], P=s["P"], om_old=s["om_old"], acc_old=s["acc_old"], q_old=s["q_old"])
     w32 = _segments(g32, wl, om, acc, dev, (10000,), first=9900, flagged=np.zeros(B, dtype=bool))[10000]
 
-    # the oracle on 16 sampled instances: free-running over the full horizon, and restarted at step 9 900
-    sample = np.linspace(0, B - 1, 16).astype(np.int64)
+    # the oracle on 64 sampled instances: free-running over the full horizon, and restarted at step 9 900
+    sample = np.linspace(0, B - 1, 64).astype(np.int64)
     prm = c_oracle.make_params(wl.cfg.model.length, wl.cfg.model.angle, wl.cfg.frozen_dofs, wl.hold_frozen, wl.sigma_a,
                                wl.sigma_om, wl.Q, wl.R)
     o = c_oracle.OracleBatch(prm, wl.x0[sample], wl.P0, wl.om0, wl.acc0)
@@ -121,7 +121,7 @@ def test_config5_ten_thousand_steps_fp64_vs_oracle_and_fp32_vs_fp64():
         e0 = e1
     from dvi_ekf_amd import rotmath as rm
     ow = c_oracle.OracleBatch(prm, s["x"][sample], s["P"][sample], s["om_old"][sample], s["acc_old"][sample])
-    for b in range(16):
+    for b in range(len(sample)):
         ow.Rwb[b] = rm.quat_to_matrix(s["q_old"][sample[b]]).reshape(9)     # R_WB_old is not Rm(x.q) after an update (Q7)
     oracle_run(ow, int(np.searchsorted(cum, 9900)) + 1, 300, 9900)
 
@@ -159,9 +159,9 @@ def test_config5_default_yaml_noise_parity_over_the_stable_horizon():
     wl = long_horizon(batch=B, n_steps=1000, meas_pos_std=None, meas_theta_deg=None)
     f = wl.make_filter(dtype=torch.float64, device=dev)
     t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
-    cps = (100, 200, 300, 400, 500, 700, 1000)
+    cps = (100, 200, 300, 400, 500, 600, 700, 800, 900, 1000)
     got = _segments(f, wl, t(wl.om), t(wl.acc), dev, cps)
-    sample = np.linspace(0, B - 1, 16).astype(np.int64)
+    sample = np.linspace(0, B - 1, 64).astype(np.int64)
     prm = c_oracle.make_params(wl.cfg.model.length, wl.cfg.model.angle, wl.cfg.frozen_dofs, wl.hold_frozen, wl.sigma_a,
                                wl.sigma_om, wl.Q, wl.R)
     o = c_oracle.OracleBatch(prm, wl.x0[sample], wl.P0, wl.om0, wl.acc0)
@@ -173,6 +173,9 @@ def test_config5_default_yaml_noise_parity_over_the_stable_horizon():
         o.update(wl.pos[e], wl.quat[e], wl.notch[e])
         if i in cps:
             curve[i] = _rel(got[i]["x"][sample], o.x)
-    print("config #5 with the default YAML noise, fp64 vs oracle, free-running: " +
-          "  ".join(f"{k}: {v:.1e}" for k, v in curve.items()))
-    assert all(v <= 1e-9 for k, v in curve.items() if k <= STABLE_STEPS)
+    holds = [k for k in cps if all(curve[j] <= 1e-9 for j in cps if j <= k)]
+    last = max(holds) if holds else 0
+    print("config #5 with the default YAML noise, fp64 vs oracle on 64 instances, free-running: " +
+          "  ".join(f"{k}: {v:.1e}" for k, v in curve.items()) + f"  -> 1e-9 holds through step {last}")
+    # (measured: 1e-9 holds through step 800 or 900 depending on the build's rounding; the asserted horizon is 700)
+    assert last >= STABLE_STEPS

@@ -1,6 +1,8 @@
-"""IMU synthesis on the device (dvi_eskf_imu_synthesize) against the host restatement
-of f_imu_meas / f_imu (dvi_ekf_amd.imu, pinned by tests/test_oracle_golden.py to the reference's saved
-IMU reference trajectory)."""
+"""IMU synthesis and trajectory-log rows on the device (dvi_eskf_imu_synthesize,
+dvi_eskf_log_rows) against the independent checker oracle/io_ref.py (numerical DH chain with the reference's Jacobian /
+Hessian contraction, literal f_imu / f_imu_meas, scipy Euler angles; pinned to the reference's saved files by
+tests/test_oracle_io_ref.py) -- and against the product's own host code (dvi_ekf_amd.imu / traj), so that device
+kernel, product host code and oracle agree pairwise."""
 import numpy as np
 import pytest
 import torch
@@ -8,6 +10,7 @@ import torch
 from dvi_ekf_amd.camera import create_camera
 from dvi_ekf_amd.imu import Imu, imu_measurement, imu_pose_from_camera, synthesize_on_device
 from dvi_ekf_amd.probe import SimpleProbe, probe_fwkin
+from oracle import io_ref
 from tests.helpers import default_run
 
 pytestmark = pytest.mark.gpu
@@ -34,15 +37,24 @@ def test_device_imu_stream_matches_host(mode):
     om_d, acc_d, p_d, R_d, v_d = synthesize_on_device(R, cam.om.T, cam.acc.T, cam.alp.T, notch, dofs, probe.scope_length,
                                                       probe.theta_cam, p_CW=cam.p.T, v_CW=cam.v.T)
     om_h, acc_h, p_h, R_h, v_h = [], [], [], [], []
+    orc = [[], [], [], [], []]
     for i in range(n):
         nt = notch[i] if notch.ndim == 2 else notch
         fk = probe_fwkin(dofs, nt, probe.scope_length, probe.theta_cam)
         o, a = imu_measurement(R[i], cam.om[:, i], cam.acc[:, i], cam.alp[:, i], fk)
         pr, Rr, vr = imu_pose_from_camera([cam.p[:, i], R[i], cam.v[:, i], cam.om[:, i], cam.acc[:, i], cam.alp[:, i]], fk)
         om_h.append(o); acc_h.append(a); p_h.append(pr); R_h.append(Rr); v_h.append(vr)
-    for name, d, h in (("om", om_d, om_h), ("acc", acc_d, acc_h), ("p_ref", p_d, p_h), ("R_ref", R_d, R_h), ("v_ref", v_d, v_h)):
+        fo = io_ref.simple_probe_fwkin(dofs, nt, probe.scope_length, probe.theta_cam)
+        oo, ao = io_ref.f_imu_meas(R[i], cam.om[:, i], cam.acc[:, i], cam.alp[:, i], fo)
+        po, Ro, vo = io_ref.f_imu(cam.p[:, i], R[i], cam.v[:, i], cam.om[:, i], fo)
+        for lst, val in zip(orc, (oo, ao, po, Ro, vo)):
+            lst.append(val)
+    for k, (name, d, h) in enumerate((("om", om_d, om_h), ("acc", acc_d, acc_h), ("p_ref", p_d, p_h), ("R_ref", R_d, R_h), ("v_ref", v_d, v_h))):
         d = d.cpu().numpy()
         h = np.array(h)
+        o = np.array(orc[k])
+        assert np.abs(d - o).max() / max(1.0, np.abs(o).max()) <= 1e-12, (name, "device vs oracle")
+        assert np.abs(h - o).max() / max(1.0, np.abs(o).max()) <= 1e-12, (name, "product host code vs oracle")
         err = np.abs(d - h).max() / max(1.0, np.abs(h).max())
         assert err <= 1e-13, (name, err)       # fp64: same formulas, different association only
 
@@ -93,6 +105,7 @@ def test_device_log_rows_match_host_log_format():
             host = np.array(euler_measurement_row(0.25 * k, State.from_vector(x[b])), dtype=float)
             scale = np.maximum(1.0, np.abs(host))
             assert (np.abs(rows[b] - host) / scale).max() <= 1e-12, (k, b)
+            assert (np.abs(rows[b] - io_ref.filter_log_row(0.25 * k, x[b])) / scale).max() <= 1e-11, (k, b, "device vs oracle")
         f.step(ri.dt[k], ri.om[k], ri.acc[k], ri.pos[k], ri.quat[k], ri.notch[k])   # leaves an injection pending
 
 
@@ -115,14 +128,20 @@ def test_device_imu_and_log_rows_at_random_configurations():
     L, th = 50.0, np.radians(30.0)
     om_d, acc_d, p_d, R_d, v_d = synthesize_on_device(R, om, acc, alp, notch, dofs, L, th, p_CW=p, v_CW=v)
     worst = 0.0
+    worst_o = 0.0
+    dev = [t.cpu().numpy() for t in (om_d, acc_d, p_d, R_d.reshape(n, 3, 3), v_d)]
     for i in range(n):
         fk = probe_fwkin(dofs, notch[i], L, th)
         o, a = imu_measurement(R[i], om[i], acc[i], alp[i], fk)
         pr, Rr, vr = imu_pose_from_camera([p[i], R[i], v[i], om[i], acc[i], alp[i]], fk)
-        for d, h in ((om_d[i], o), (acc_d[i], a), (p_d[i], pr), (R_d[i].reshape(3, 3), Rr), (v_d[i], vr)):
+        fo = io_ref.simple_probe_fwkin(dofs, notch[i], L, th)
+        oracle_vals = (*io_ref.f_imu_meas(R[i], om[i], acc[i], alp[i], fo), *io_ref.f_imu(p[i], R[i], v[i], om[i], fo))
+        for d, h, o_ in zip((dev[0][i], dev[1][i], dev[2][i], dev[3][i], dev[4][i]), (o, a, pr, Rr, vr), oracle_vals):
             h = np.asarray(h, dtype=float).reshape(d.shape)
-            worst = max(worst, np.abs(d.cpu().numpy() - h).max() / max(1.0, np.abs(h).max()))
+            worst = max(worst, np.abs(d - h).max() / max(1.0, np.abs(h).max()))
+            worst_o = max(worst_o, np.abs(d - np.asarray(o_).reshape(d.shape)).max() / max(1.0, np.abs(np.asarray(o_)).max()))
     assert worst <= 1e-13, worst
+    assert worst_o <= 1e-12, worst_o            # device vs the independent oracle
 
     B = 256
     cfg, ri, Q, Rm, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)

@@ -100,7 +100,7 @@ def _innovation_condition(P, R):
 # header.  All three start from the same SYMMETRIC covariance (see the test): the exact update of an
 # ill-conditioned instance moves by 1e-8 when the last bit of P's asymmetry is dropped, which would otherwise
 # be charged to whoever stores P packed.
-C_REF, C_COND = 2.0, 4.0
+C_REF, C_COND = 2.0, 1.0          # (measured: never more than 0.3 cond(S) eps over every update of this file and of test_gpu_scale.py)
 FLOOR_X, FLOOR_P = 1e-11, 1e-10
 EPS = 2.0 ** -52
 
@@ -213,7 +213,53 @@ def test_forced_single_step_parity(golden, frozen, nframes):
           f"closest call x: gpu {worst['x_gpu']:.1e} vs fp64 oracle {worst['x_ref']:.1e} from exact (cond {worst['kappa']:.1e}), "
           f"P: gpu {worst['P_gpu']:.1e} vs {worst['P_ref']:.1e}; largest cond {worst['kmax']:.1e}, "
           f"largest gpu error / (cond eps) where cond > 1e3: {worst['ratio']:.1f}")
+    assert n_cmp > 0                        # (the direct fp64 comparisons above are maxima over a non-empty set)
     assert ex <= 1e-11 and eP <= 1e-10 and eK <= 1e-8 and eres <= 1e-10
+
+
+def test_packed_covariance_sensitivity_to_the_oracle_s_raw_asymmetric_P():
+    """What the symmetric-packed storage of P costs, pinned instead of argued (parity caveat 2).  The
+    golden-compat 1:1 run with unfrozen DOFs, 20 frames (cond(S) up to ~2e6, |x| up to 1e3): at every update the
+    fp64 oracle and the extended-precision adjudicator keep the oracle's RAW predicted covariance -- `Fx P Fx^T` in
+    plain triple loops, asymmetric at the 1e-16 |P| level -- while the GPU is handed that same matrix and stores its
+    lower triangle.  The exact update of an ill-conditioned instance is sensitive to that last bit, so the GPU's
+    distance from the adjudicator is no longer bounded by cond(S) eps times a small constant; measured on this run:
+    x up to 1.2e-8 at cond 1.6e6, i.e. up to ~40 cond(S) eps.  Asserted here: the
+    distance stays below 100 cond(S) eps + the well-conditioned floor for every instance and frame, and is below
+    the 1e-9 target of the path wherever cond(S) <= 1e4."""
+    B = 16
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=False, frozen=(0,) * 6, interframe=1)
+    x0 = _perturbed_x0(ri, B)
+    f = _make(cfg, ri, Q, R, sa, so, B, True, x0)
+    o = _oracle(cfg, ri, Q, R, sa, so, B, True, x0)
+    h = _oracle(cfg, ri, Q, R, sa, so, B, True, x0, hp=True)
+    q_old = o.x[:, 6:10].copy()
+    worst_ratio, worst_x, worst_asym, worst_sane = 0.0, 0.0, 0.0, 0.0
+    for k in range(20):
+        o.predict(ri.dt[k], ri.om[k], ri.acc[k])                    # (1:1 schedule: one predict per frame)
+        q_old_next = o.x[:, 6:10].copy()
+        P_raw = o.P.copy()                                           # NOT symmetrised
+        worst_asym = max(worst_asym, float((np.abs(P_raw - np.transpose(P_raw, (0, 2, 1))).reshape(B, -1).max(axis=1)
+                                            / np.abs(P_raw).reshape(B, -1).max(axis=1)).max()))
+        f.set_state(x=o.x, P=P_raw, om_old=o.om_old, acc_old=o.acc_old, q_old=q_old_next)
+        h.x[:], h.P[:] = o.x, P_raw
+        kappa = innovation_conditions(P_raw, R)
+        st, _ = f.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        assert (st.cpu().numpy() == 0).all()
+        assert (h.update(ri.pos[k], ri.quat[k], ri.notch[k]) == 0).all()
+        o.update(ri.pos[k], ri.quat[k], ri.notch[k])
+        s = {k_: v.cpu().numpy() for k_, v in f.get_state(("x", "P")).items()}
+        dx, dP = _rel_rows(s["x"], h.x), _rel_rows(s["P"], h.P)
+        d = np.maximum(dx, dP)
+        assert (d <= FLOOR_P + 100.0 * kappa * EPS).all(), (k, int(np.argmax(d / (kappa * EPS))), d.max(), kappa.max())
+        worst_ratio = max(worst_ratio, float((d / (kappa * EPS))[kappa > 1e3].max(initial=0.0)))
+        worst_x = max(worst_x, float(dx.max()))
+        if (kappa <= 1e4).any():
+            worst_sane = max(worst_sane, float(d[kappa <= 1e4].max()))
+        q_old = q_old_next
+    print(f"raw (asymmetric, {worst_asym:.1e} relative) predicted P handed to the packed storage: GPU up to {worst_x:.1e} from the exact "
+          f"update in x, {worst_ratio:.1f} cond(S) eps where cond > 1e3; {worst_sane:.1e} where cond <= 1e4")
+    assert worst_sane <= 1e-9
 
 
 @pytest.mark.parametrize("golden,frozen,nframes,horizon", [(True, (1,) * 6, 40, 30), (False, (1,) * 6, 50, 40),
