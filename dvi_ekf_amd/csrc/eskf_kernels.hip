@@ -552,6 +552,15 @@ __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64
 // instruction, read-wait-store 144 us; this version 118 us; no stores at all 72 us; the same bytes as 67
 // one-word-per-lane instructions (conflict-free LDS reads) 213 us; as 17 instructions with all 64 lanes busy
 // (pieces of up to four records per instruction) 183 us.
+template <typename P>
+__device__ __forceinline__ void st_piece(P* dst, const P& v) {
+#ifdef ESKF_X_NT_RECORDS    // experiment: the records are written once and read once by the next kernel -- non-temporal stores
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    __builtin_nontemporal_store(__builtin_bit_cast(u4, v), reinterpret_cast<u4*>(dst));
+#else
+    *dst = v;
+#endif
+}
 template <typename T, int JS>
 __device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int lane, int first = 0) {
     constexpr int PW = 16 / (int)sizeof(T);             // words per piece
@@ -574,14 +583,14 @@ __device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int 
         for (int u = 0; u < 8; ++u) fetch(r0 + u * RPI + rs, v[u]);
         asm volatile("" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < 8; ++u) *reinterpret_cast<Piece*>(dst + (int64_t)(r0 + u * RPI + rs) * JW) = v[u];
+        for (int u = 0; u < 8; ++u) st_piece(reinterpret_cast<Piece*>(dst + (int64_t)(r0 + u * RPI + rs) * JW), v[u]);
     }
     for (; r0 < nrec; r0 += RPI) {                      // the rest (and the last block of a ragged batch)
         const int r = r0 + rs;
         if (r < nrec) {
             Piece v;
             fetch(r, v);
-            *reinterpret_cast<Piece*>(dst + (int64_t)r * JW) = v;
+            st_piece(reinterpret_cast<Piece*>(dst + (int64_t)r * JW), v);
         }
     }
 }
@@ -2638,6 +2647,11 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
+#ifdef ESKF_X_NT_JLOADS     // experiment: records are read exactly once
+#define ESKF_LDJ(p) __builtin_nontemporal_load(p)
+#else
+#define ESKF_LDJ(p) (*(p))
+#endif
 template <typename T, bool PIN, int LPI, bool SLIM>
 __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams<T>& prm, T* smem, const int vblock, const int lane) {
     auto gsync = [&]() { group_sync(); };
@@ -2686,7 +2700,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
         _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
             const int w_ = LPI == 32 ? lj_ + 32 * k : kRowsTables.jsrc[TV][lj_][k];   /* (same numbers) */ \
-            DST[k] = gJ_[w_ < jlast ? w_ : jlast];   /* (the padding of the record is not fetched) */ \
+            DST[k] = ESKF_LDJ(gJ_ + (w_ < jlast ? w_ : jlast));   /* (the padding of the record is not fetched) */ \
         }                                                                                          \
         /* (32 lanes per instance: the residual is words 0..7 of the first record, i.e. already in DST[0]) */ \
         if constexpr (LPI != 32) RES.x = (reinterpret_cast<const T*>(a.J) + (int64_t)(INST) * JW + J_RES)[lj_ & 7]; \
@@ -2830,11 +2844,19 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     }
 
     // ================================ predict(s) =======================================
+    // (ESKF_X_NO_PREDICT / ESKF_X_NO_UPDATE, `make EXTRA=-D...`: timing builds with a part compiled out -- what the
+    //  memory skeleton of the kernel costs on its own, profiles/r03_cov_phase_variants.json; wrong results, of course)
+#ifdef ESKF_X_NO_PREDICT
+    const int n_pred_run = 0;
+    asm volatile("" : : "v"(Jr.X[0]), "v"(Jr.Y[1]), "v"(Jr.Y[2]));      // (the record is still fetched)
+#else
+    const int n_pred_run = a.n_pred;
+#endif
     if constexpr (DPPJ) {
         // epochs: the record of the next predict is requested before this one is computed (six registers)
         // and put in place after it; the last (or only) predict of a launch has nothing to fetch
-        for (int ip = 0; ip < a.n_pred; ++ip) {
-            const bool more = ip + 1 < a.n_pred;    // uniform
+        for (int ip = 0; ip < n_pred_run; ++ip) {
+            const bool more = ip + 1 < n_pred_run;    // uniform
             T jn[NJ];
             T2 rn;
             rn.x = rn.y = T(0);
@@ -2848,7 +2870,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             }
         }
     } else {
-        for (int ip = 0; ip < a.n_pred; ++ip) {
+        for (int ip = 0; ip < n_pred_run; ++ip) {
             if (ip > 0) {                   // (the first record was staged before the loop)
                 T jn[NJ];
                 T2 rn;
@@ -2876,7 +2898,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     T e = T(0);                             // component `row` of the error state
     int status = 0;
     bool fail = false;
-    if (a.do_update) {
+#ifdef ESKF_X_NO_UPDATE
+    const bool do_update_run = false;
+#else
+    const bool do_update_run = a.do_update != 0;
+#endif
+    if (do_update_run) {
         constexpr bool DPPU = LPI == 32;
         if constexpr (DPPU) status = (dpp_bcast<7>(Xres) != T(0)) ? DVI_STATUS_NONFINITE : 0;
         else status = (sR[7] != T(0)) ? DVI_STATUS_NONFINITE : 0;
@@ -2985,7 +3012,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         }
     }
 
-    if (a.do_update) {
+    if (do_update_run) {
         const bool upd = !fail;
         if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
         if (upd && active) {
@@ -3413,7 +3440,11 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? JB_FULL : JB_CORE) + 9) * sizeof(T);    // + parked measurement
     if (a.n_pred == 1 && !g_pre_legacy) {
+#ifdef ESKF_X_PRE4_LDS      // experiment: a larger LDS request = fewer blocks per CU = more, shorter generations
+        const size_t stage4 = ESKF_X_PRE4_LDS;
+#else
         const size_t stage4 = (size_t)64 * (prm.jfull ? J_FULL : J_CORE) * sizeof(T);
+#endif
         hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
     } else if (a.n_pred == 1)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);

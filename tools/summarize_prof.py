@@ -3,6 +3,8 @@ under profiles/.  usage: summarize_prof.py <tag> <kernel-trace dir> [<fetch pmc 
 import collections, csv, glob, json, os, sys
 
 tag, kdir = sys.argv[1], sys.argv[2]
+KEYS = ("eskf_step_kernel", "eskf_pre_kernel", "eskf_pre4_kernel", "eskf_nominal_kernel", "eskf_jac_kernel", "eskf_cov_kernel",
+        "eskf_cov_rows_kernel", "eskf_post_kernel")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -18,7 +20,7 @@ res = {"tag": tag}
 if trace:
     allrows = list(csv.DictReader(open(trace[0])))
     res["step_kernels"] = {}
-    for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_cov_rows_kernel", "eskf_post_kernel"):
+    for key in KEYS:
         t = [r for r in allrows if key in r["Kernel_Name"]]
         if not t:
             continue
@@ -42,7 +44,7 @@ if len(sys.argv) >= 5:
             acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         pm[name] = {}
         for k, v in acc.items():
-            for key in ("eskf_step_kernel", "eskf_pre_kernel", "eskf_cov_kernel", "eskf_cov_rows_kernel", "eskf_post_kernel"):
+            for key in KEYS:
                 if key in k:
                     pm[name][key] = {"launches": len(v), "mean_KiB": sum(v) / len(v), "min_KiB": min(v), "max_KiB": max(v)}
             if "copyBuffer" in k:
