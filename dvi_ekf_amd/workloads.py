@@ -158,6 +158,10 @@ class LongHorizonWorkload:
     cam_inputs: dict      # what dvi_eskf_imu_synthesize consumes: R_WC [N+1,3,3], om/acc/alp [N+1,3] (sample 0 = t0)
     dofs_gt: np.ndarray   # [6]
     hold_frozen: bool = True
+    # what was changed against the default config.yaml (None = the YAML's value): reported next to every number measured
+    # on this workload -- with the YAML's camera noise the reference filter stays bounded for ~800 steps only
+    meas_pos_std: object = None
+    meas_theta_deg: object = None
 
     @property
     def n_steps(self) -> int:
@@ -265,4 +269,4 @@ def long_horizon(batch: int = 8192, n_steps: int = 10000, imu_hz: float = 1000.0
         om=om_all[1: n_use + 1].copy(), acc=acc_all[1: n_use + 1].copy(), t_imu=t_imu_all[1: n_use + 1].copy(),
         pos=np.array([m.pos for m in meas]), quat=np.array([m.q.xyzw for m in meas]), notch=np.zeros(E),
         t_meas=np.asarray(cam.t[1: E + 1], dtype=float), cam_inputs=cam_inputs, dofs_gt=np.array(probe.imu_dofs, dtype=float),
-        hold_frozen=bool(hold_frozen))
+        hold_frozen=bool(hold_frozen), meas_pos_std=meas_pos_std, meas_theta_deg=meas_theta_deg)
