@@ -2329,9 +2329,35 @@ __device__ __forceinline__ void fx_apply_col(const T* sJ, const T* col, T (&o)[2
 // P' += Fi Q Fi^T on the row-resident P: diagonal entries 3..14 <- Q[i-3], 17 <- Q[12]
 // (Filter.py:263-264,349); with gyro noise (tune mode) also the camera rows through N6 and theta
 // through Fi[6:9,3:6] = I
-template <typename T, bool PIN, bool GYRO = true>
+template <int J0, int J1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (J0 < J1) {
+        f(std::integral_constant<int, J0>{});
+        static_for<J0 + 1, J1>(f);
+    }
+}
+// p += q in the lanes that own row ROW of an instance in the 32-lanes-per-instance layout (lanes ROW and 32 + ROW): a
+// constant of the layout, so the add runs under a constant EXEC mask -- one vector instruction per diagonal element
+// instead of a compare, two selects and an add (the select chain below spends ~78 instructions per predict on
+// adding one number to the lane's diagonal element)
+template <int ROW>
+__device__ __forceinline__ void add_in_row_lanes(double& p, double q) {
+    constexpr unsigned long long mask = (1ull << ROW) | (1ull << (32 + ROW));
+    unsigned long long saved;
+    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask));
+}
+template <int ROW>
+__device__ __forceinline__ void add_in_row_lanes(float& p, float q) {
+    constexpr unsigned long long mask = (1ull << ROW) | (1ull << (32 + ROW));
+    unsigned long long saved;
+    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f32 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask));
+}
+template <typename T, bool PIN, bool GYRO = true, bool LANES32 = false>
 __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, const T* sN, int row, T (&p)[24]) {
-    if (PIN) {      // diag(Q) of this instance sits in LDS (sN[0:13]); each lane needs the entry of its own row
+    if constexpr (!PIN && LANES32) {
+        static_for<0, 12>([&](auto K) { add_in_row_lanes<3 + decltype(K)::value>(p[3 + decltype(K)::value], prm.qd[decltype(K)::value]); });
+        add_in_row_lanes<17>(p[17], prm.qd[12]);
+    } else if (PIN) {      // diag(Q) of this instance sits in LDS (sN[0:13]); each lane needs the entry of its own row
         T qrow = T(0);
         if (row >= 3 && row < 15) qrow = sN[row - 3];
         if (row == 17) qrow = sN[12];
@@ -2432,13 +2458,6 @@ __device__ __forceinline__ float dpp_bcast(float src) {
     float r;
     asm("v_mov_b32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(LANE));
     return r;
-}
-template <int J0, int J1, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (J0 < J1) {
-        f(std::integral_constant<int, J0>{});
-        static_for<J0 + 1, J1>(f);
-    }
 }
 // float overloads: never instantiated on a taken path (the fp32 kernels keep the LDS exchange)
 // The Jacobian record of an instance spread over its 32 lanes (lane l holds words l, 32+l, 64+l -- the
@@ -2805,7 +2824,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         gsync();                                                                              \
         if constexpr (DPPJ) fx_apply_col_dpp(Jr, sB + row, p);                                     \
         else fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */     \
-        noise_rows<T, PIN, !SLIM>(prm, sJ, sN, row, p);                                            \
+        noise_rows<T, PIN, !SLIM, LPI == 32>(prm, sJ, sN, row, p);                                 \
         gsync();                                                                              \
     }
     const bool valid = slot < nB;           // tail: recompute the last instance, write nothing
@@ -2820,8 +2839,15 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         T j0[NJ];
         T2 r0;
         r0.x = r0.y = T(0);
+#ifdef ESKF_X_PRIO
+        __builtin_amdgcn_s_setprio(3);      // a new wavefront is the youngest on its SIMD: let it get its requests out
+#endif
         ESKF_ISSUE_ROW()
         ESKF_LOAD_J(j0, r0, inst, 0)
+#ifdef ESKF_X_PRIO
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+#endif
         ESKF_STAGE_J(j0, r0)
         if (PIN || !SLIM) gsync();      // (what has been staged -- noise record, N6 rows -- is visible to every lane)
     } else {
@@ -3076,6 +3102,9 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     }
 
     // ---- store: rows -> lower-triangle image -> packed record (16-byte stores) ----------------
+#if defined(ESKF_X_PRIO) && ESKF_X_PRIO >= 2
+    __builtin_amdgcn_s_setprio(2);          // ... and let a finished one leave
+#endif
     if (active) {   // (the whole row: the words above the diagonal are never read)
 #pragma unroll
         for (int j = 0; j < 24; ++j) lds_store1(sB + row * PS + j, p[j]);
