@@ -13,7 +13,7 @@
 #include "eskf_device.h"
 
 #ifdef ESKF_X_STAMPS
-namespace eskf { hipError_t x_read_stamps(unsigned long long* out); }
+namespace eskf { hipError_t x_read_stamps(unsigned long long* out); hipError_t x_read_cstamps(unsigned long long* out); }
 #endif
 
 struct dvi_eskf {
@@ -607,6 +607,7 @@ int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, 
 
 #ifdef ESKF_X_STAMPS
 int dvi_eskf_x_stamps(unsigned long long* out) { return eskf::x_read_stamps(out) == hipSuccess ? 0 : -4; }
+int dvi_eskf_x_cstamps(unsigned long long* out) { return eskf::x_read_cstamps(out) == hipSuccess ? 0 : -4; }
 #endif
 
 const char* dvi_eskf_strerror(int code) {

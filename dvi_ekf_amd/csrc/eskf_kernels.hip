@@ -914,10 +914,14 @@ __device__ __forceinline__ void jac_blocks_attitude(const DevParams<T>& prm, con
 // ----------------------------------------------------------------------------------
 #ifdef ESKF_X_STAMPS        // diagnostic build only: wall-clock stamps (100 MHz) of every block of the last pre4 launch
 __device__ unsigned long long g_x_stamps[8 * 4096];
+__device__ unsigned long long g_c_stamps[8 * 4096];      // covariance kernel: every eighth block
+hipError_t x_read_cstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c_stamps), sizeof(g_c_stamps)); }
 #define ESKF_STAMP(K) { if (lane == 0 && vblock < 4096) g_x_stamps[(K) * 4096 + vblock] = __builtin_amdgcn_s_memrealtime(); }
+#define ESKF_CSTAMP(K) { if (lane == 0 && (vblock & 7) == 0 && (vblock >> 3) < 4096) g_c_stamps[(K) * 4096 + (vblock >> 3)] = __builtin_amdgcn_s_memrealtime(); }
 hipError_t x_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x_stamps), sizeof(g_x_stamps)); }
 #else
 #define ESKF_STAMP(K) {}
+#define ESKF_CSTAMP(K) {}
 #endif
 // exchange words of a lane sit in its own staging row, on block words that are only written after barrier 1b
 constexpr int PRE4_XOFF = J_BM;
@@ -2833,6 +2837,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     asm volatile("" : "+v"(row), "+v"(inst));
     constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
     T p[24];                                // row `row` of P
+    ESKF_CSTAMP(0)
     if constexpr (DPPJ && sizeof(T) == 8) {
         // everything this wavefront reads is requested in one go -- the 24 row elements first, then the
         // Jacobian record and the residual -- and waited for once: one memory round trip, not two
@@ -2863,6 +2868,11 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     // 32 lanes per instance: residual (7) and non-finite flag of the update are words 0..7 of the first predict's
     // record -- lanes 0..7 of the first 16-lane row of its first register, which spread_rows() has just made
     // available to both rows: the update takes them as DPP operands (no separate load, no LDS staging)
+#ifdef ESKF_X_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pin_row(p);
+#endif
+    ESKF_CSTAMP(1)
     T Xres = T(0);
     if constexpr (DPPJ) {
         Xres = Jr.X[0];
@@ -2921,6 +2931,10 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
 #pragma unroll
     for (int k = 0; k < 2 * NV; ++k) asm volatile("" : "+v"(off[k]));
 
+#ifdef ESKF_X_STAMPS
+    pin_row(p);
+#endif
+    ESKF_CSTAMP(2)
     T e = T(0);                             // component `row` of the error state
     int status = 0;
     bool fail = false;
@@ -3038,21 +3052,37 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         }
     }
 
+#ifdef ESKF_X_STAMPS
+    pin_row(p);
+#endif
+    ESKF_CSTAMP(3)
     if (do_update_run) {
         const bool upd = !fail;
         if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
+        constexpr bool DPPR = LPI == 32;    // the six attitude components of the error state reach every lane as DPP operands
         if (upd && active) {
-            sC[row] = e;
+            if constexpr (!DPPR) sC[row] = e;
             if (valid) reinterpret_cast<T*>(a.e)[(int64_t)inst * 24 + row] = e;
         }
-        gsync();
+        T Gt[3] = {T(0), T(0), T(0)}, Gc[3] = {T(0), T(0), T(0)};
+        if constexpr (DPPR) {
+            // (one LDS round trip and one barrier less than publishing e: rows 6..8 sit in the first 16-lane row of
+            //  the instance, rows 21..23 in lanes 5..7 of the second)
+            T Xe, Ye;
+            spread_rows(e, Xe, Ye);
+            Gt[0] = T(0.5) * dpp_bcast<6>(Xe); Gt[1] = T(0.5) * dpp_bcast<7>(Xe); Gt[2] = T(0.5) * dpp_bcast<8>(Xe);
+            Gc[0] = T(0.5) * dpp_bcast<5>(Ye); Gc[1] = T(0.5) * dpp_bcast<6>(Ye); Gc[2] = T(0.5) * dpp_bcast<7>(Ye);
+        } else {
+            gsync();
+        }
         T* sY = sB;     // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
         if (upd) {
             // ---- reset G P G^T (Filter.py:387-390), G = I - [theta/2]x on 6:9 and 21:24.
             // column part, in registers
-            T Gt[3], Gc[3];
+            if constexpr (!DPPR) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { Gt[k] = T(0.5) * sC[6 + k]; Gc[k] = T(0.5) * sC[21 + k]; }
+                for (int k = 0; k < 3; ++k) { Gt[k] = T(0.5) * sC[6 + k]; Gc[k] = T(0.5) * sC[21 + k]; }
+            }
             const T a0 = p[6], a1 = p[7], a2 = p[8];
             p[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
             p[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
@@ -3078,7 +3108,9 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             const int tb = lo ? 6 : 21;
             const int t = row - tb;
             const int sw = lo ? t : 4 + t;
-            const T g0 = T(0.5) * sC[tb], g1 = T(0.5) * sC[tb + 1], g2 = T(0.5) * sC[tb + 2];   // (read again: not kept across)
+            T g0, g1, g2;
+            if constexpr (DPPR) { g0 = lo ? Gt[0] : Gc[0]; g1 = lo ? Gt[1] : Gc[1]; g2 = lo ? Gt[2] : Gc[2]; }
+            else { g0 = T(0.5) * sC[tb]; g1 = T(0.5) * sC[tb + 1]; g2 = T(0.5) * sC[tb + 2]; }   // (read again: not kept across)
             const T k0 = (t == 0) ? T(1) : (t == 1) ? -g2 : g1;
             const T k1 = (t == 0) ? g2 : (t == 1) ? T(1) : -g0;
             const T k2 = (t == 0) ? -g1 : (t == 1) ? g0 : T(1);
@@ -3101,6 +3133,10 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         }
     }
 
+#ifdef ESKF_X_STAMPS
+    pin_row(p);
+#endif
+    ESKF_CSTAMP(4)
     // ---- store: rows -> lower-triangle image -> packed record (16-byte stores) ----------------
 #if defined(ESKF_X_PRIO) && ESKF_X_PRIO >= 2
     __builtin_amdgcn_s_setprio(2);          // ... and let a finished one leave
@@ -3128,6 +3164,11 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             if (e2 < 150) gP2[e2] = v[k];
         }
     }
+    ESKF_CSTAMP(5)
+#ifdef ESKF_X_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    ESKF_CSTAMP(6)
 #undef ESKF_LOAD_J
 #undef ESKF_STAGE_J
 #undef ESKF_UNPACK_ROW

@@ -25,3 +25,17 @@ names = ["start", "loads arrived", "phase A done", "past barrier 1", "phase B do
 for k in range(8):
     v = (st[k] - t0) / 100.0
     print(f"{names[k]:16s} median {np.median(v):7.2f}  min {v.min():7.2f}  max {v.max():7.2f}  p10 {np.percentile(v,10):7.2f} p90 {np.percentile(v,90):7.2f} us")
+
+buf = np.zeros(8 * 4096, dtype=np.uint64)
+fn = L.dvi_eskf_x_cstamps; fn.restype = C.c_int; fn.argtypes = [C.c_void_p]
+assert fn(buf.ctypes.data) == 0
+nc = min(4096, (B // 2 + 7) // 8)
+st = buf.reshape(8, 4096)[:, :nc].astype(np.int64)
+t0 = st[0].min()
+print("covariance kernel (every eighth wavefront): per-wavefront durations of the phases, us")
+names = ["load (rows + record)", "predict", "update", "reset", "store issue", "store ack"]
+for k in range(6):
+    v = (st[k + 1] - st[k]) / 100.0
+    print(f"{names[k]:22s} median {np.median(v):6.2f}  p10 {np.percentile(v,10):6.2f}  p90 {np.percentile(v,90):6.2f}")
+life = (st[6] - st[0]) / 100.0
+print(f"wavefront life          median {np.median(life):6.2f}  p10 {np.percentile(life,10):6.2f}  p90 {np.percentile(life,90):6.2f};  kernel span {(st[6].max() - t0) / 100.0:.1f} us; starts: median {np.median((st[0]-t0)/100.0):.1f}")
