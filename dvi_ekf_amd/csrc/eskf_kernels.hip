@@ -454,6 +454,9 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
 template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
+template <typename T> struct Vec16;     // a 16-byte piece of a record
+template <> struct Vec16<double> { using type = double2; };
+template <> struct Vec16<float> { using type = float4; };
 
 // One record per instance and predict: the residual of the launch's update (7 words + the non-finite flag; record
 // of the FIRST predict only) followed by the blocks in the member order of Jac<T>:
@@ -2624,7 +2627,8 @@ __device__ __forceinline__ unsigned select_lanes_ge(int J, unsigned a, unsigned 
 //                  (pieces lig, lig+32, ... of 16 bytes; the last piece is clamped to the record's end)
 //   gat[row][24]   image position of P[row][j] in the lower-triangle image: max(row,j)*25 + min(row,j)
 struct RowsTables {                  // [v]: lane layout v = 0: 32 lanes per instance, v = 1: 24 lanes per instance
-    int pos[2][32][16];
+    int pos[2][32][16];  // fp64: 16-byte pieces of two words
+    int pos4[2][32][16]; // fp32: 16-byte pieces of four words (75 per record)
     int gat[24][24];
     int jsrc[2][32][4];  // Jacobian record: the record words lane lig moves (clamped to the record) ...
     int jdst[2][32][4];  // ... and where they go in the LDS copy (blocks re-laid on even offsets, lds_word)
@@ -2642,6 +2646,10 @@ constexpr RowsTables make_rows_tables() {
                 const int e2r = l + lpi * k, e2 = e2r < 150 ? e2r : 149;
                 t.pos[v][l][2 * k] = packed_image_pos(2 * e2);
                 t.pos[v][l][2 * k + 1] = packed_image_pos(2 * e2 + 1);
+            }
+            for (int k = 0; k < 4; ++k) {
+                const int e4r = l + lpi * k, e4 = e4r < 75 ? e4r : 74;
+                for (int c = 0; c < 4; ++c) t.pos4[v][l][4 * k + c] = packed_image_pos(4 * e4 + c);
             }
             for (int k = 0; k < 4; ++k) {
                 const int wr = l + lpi * k, w = wr < JW ? wr : JW - 1, b = w - J_B0;
@@ -2703,8 +2711,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     const int jlast = prm.q_gyro ? J_FULL - 1 : J_CORE - 1;
     const int jlast_lds = prm.q_gyro ? L_N6 + 17 : L_DUMP;   // (everything past dt goes to the pad word)
     constexpr int NJ = (JW + LPI - 1) / LPI;
-    constexpr int NV = (150 + LPI - 1) / LPI;
+    constexpr int PW = 16 / (int)sizeof(T);         // words per 16-byte piece of the packed record: 2 (fp64) or 4 (fp32)
+    constexpr int NPC = 300 / PW;                   // pieces per record: 150 or 75
+    constexpr int NV = (NPC + LPI - 1) / LPI;       // pieces per lane
     using T2 = typename Vec2<T>::type;
+    using TP = typename Vec16<T>::type;
+    auto piece_pos = [&](int k) { return sizeof(T) == 8 ? kRowsTables.pos[TV][lig][k] : kRowsTables.pos4[TV][lig][k]; };
 
     // one wavefront = two instances, start to finish (waves that loop over several instances with a
     // register prefetch of the next record were measured 2 % slower at three waves per SIMD: the other
@@ -2802,18 +2814,17 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             }                                                                                      \
             gsync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
         } else {                                                                                   \
-            const T2* gP2_ = reinterpret_cast<const T2*>(gP_);                                     \
-            T2 pv_[NV];                                                                            \
-            int off_[2 * NV], gat_[24];                                                            \
+            const TP* gPp_ = reinterpret_cast<const TP*>(gP_);                                     \
+            TP pv_[NV];                                                                            \
+            int off_[PW * NV], gat_[24];                                                           \
             _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                       \
-                const int e2 = lig + k * LPI;                                                      \
-                pv_[k] = gP2_[e2 < 150 ? e2 : 149];                                                \
+                const int e_ = lig + k * LPI;                                                      \
+                pv_[k] = gPp_[e_ < NPC ? e_ : NPC - 1];                                            \
             }                                                                                      \
-            _Pragma("unroll") for (int k = 0; k < 2 * NV; ++k) off_[k] = kRowsTables.pos[TV][lig][k]; \
+            _Pragma("unroll") for (int k = 0; k < PW * NV; ++k) off_[k] = piece_pos(k);            \
             _Pragma("unroll") for (int j = 0; j < 24; ++j) gat_[j] = kRowsTables.gat[row][j];      \
             _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                       \
-                sB[off_[2 * k]] = pv_[k].x;                                                        \
-                sB[off_[2 * k + 1]] = pv_[k].y;                                                    \
+                _Pragma("unroll") for (int c = 0; c < PW; ++c) sB[off_[PW * k + c]] = reinterpret_cast<const T*>(&pv_[k])[c]; \
             }                                                                                      \
             gsync();                                                                          \
             _Pragma("unroll") for (int j = 0; j < 24; ++j) p[j] = sB[gat_[j]];                     \
@@ -2925,11 +2936,11 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     // remaining measurements are skipped and the ones already applied are taken back.
     // image positions of the packed-record words this lane will store, fetched now (table in memory): asked
     // for at the point of use they cost every wavefront an exposed round trip right before its stores
-    int off[2 * NV];
+    int off[PW * NV];
 #pragma unroll
-    for (int k = 0; k < 2 * NV; ++k) off[k] = kRowsTables.pos[TV][lig][k];
+    for (int k = 0; k < PW * NV; ++k) off[k] = piece_pos(k);
 #pragma unroll
-    for (int k = 0; k < 2 * NV; ++k) asm volatile("" : "+v"(off[k]));
+    for (int k = 0; k < PW * NV; ++k) asm volatile("" : "+v"(off[k]));
 
 #ifdef ESKF_X_STAMPS
     pin_row(p);
@@ -3150,18 +3161,18 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         // (all the reads of the image first, then the stores: read-wait-store per piece is five LDS round trips
         //  in a row at the very end of the wavefront's life; the last piece's index is clamped instead of
         //  predicated so that the reads are unconditional)
-        T2* gP2 = reinterpret_cast<T2*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
-        T2 v[NV];
+        TP* gPp = reinterpret_cast<TP*>(reinterpret_cast<T*>(a.P) + (int64_t)inst * 300);
+        TP v[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            v[k].x = lds_load1(sB + off[2 * k]);
-            v[k].y = lds_load1(sB + off[2 * k + 1]);
+#pragma unroll
+            for (int c = 0; c < PW; ++c) reinterpret_cast<T*>(&v[k])[c] = lds_load1(sB + off[PW * k + c]);
         }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int e2 = lig + k * LPI;
-            if (e2 < 150) gP2[e2] = v[k];
+            const int e_ = lig + k * LPI;
+            if (e_ < NPC) gPp[e_] = v[k];
         }
     }
     ESKF_CSTAMP(5)
