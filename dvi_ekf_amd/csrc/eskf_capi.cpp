@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 #include <cstring>
 #include <new>
@@ -38,11 +39,32 @@ struct dvi_eskf {
                         // state behind the host's back, so from then on the hint is always "maybe"
     void* d_noise;      // nullable [B][NOISE_WORDS]: per-instance diag(Q) | diag(R) | sigma_om
     int jac_ip;         // record of the last predict in d_J when it was written in full (keep_jac), else -1
+    // dvi_eskf_run_epochs on an under-filled batch: the two halves of the batch run their epochs on two streams of the
+    // handle's own, forked from and joined to the caller's stream by events (created at first use)
+    hipStream_t side[2];
+    hipEvent_t ev_fork, ev_join[2];
+    bool side_ready;
 };
 
 namespace {
 
 size_t elem_size(int dtype) { return dtype == DVI_ESKF_F64 ? sizeof(double) : sizeof(float); }
+
+void free_side_streams(dvi_eskf* h) {
+    if (!h->side_ready) return;
+    for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(h->side[i]); (void)hipEventDestroy(h->ev_join[i]); }
+    (void)hipEventDestroy(h->ev_fork);
+    h->side_ready = false;
+}
+bool ensure_side_streams(dvi_eskf* h) {
+    if (h->side_ready) return true;
+    bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i)
+        ok = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    h->side_ready = ok;     // (a partial failure leaks a handle or two of a process that is out of resources anyway)
+    return ok;
+}
 
 void free_buffers(dvi_eskf* h) {
     if (h->d_P) (void)hipFree(h->d_P);
@@ -155,7 +177,7 @@ int flush_pending(dvi_eskf* h, hipStream_t stream) {
 
 int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_pi, const void* om, const void* acc,
                 int imu_pi, const void* pos, const void* quat, const void* notch, int meas_pi, void* K_out,
-                int32_t* status, void* stream, dvi_eskf* src = nullptr) {
+                int32_t* status, void* stream, dvi_eskf* src = nullptr, int64_t sub_first = 0, int64_t sub_count = 0) {
     if (!h) return DVI_ESKF_EINVAL;
     if (src == h) src = nullptr;
     if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
@@ -178,6 +200,8 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     a.imu_stride = imu_pi ? 1 : 0;
     a.meas_stride = meas_pi ? 1 : 0;
     a.pending_hint = (h->maybe_pending || h->captured) ? 1 : 0;
+    a.sub_first = sub_first;
+    a.sub_count = sub_count;
     if (src) {      // read the other handle's (flushed) state; whatever this handle held is replaced
         if (flush_pending(src, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
         a.P_src = src->d_P;
@@ -208,6 +232,7 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     if (!h) return DVI_ESKF_ENOMEM;
     h->B = batch; h->dtype = dtype; h->device = device; h->lpi = 1; h->d_noise = nullptr;
     h->maybe_pending = false; h->captured = false; h->jac_ip = -1;
+    h->side_ready = false;
     h->hp.q_gyro_any = 0; h->hp.keep_jac = 0;
     h->hp.L = p->L; h->hp.theta_cam = p->theta_cam;
     h->hp.frozen_mask = 0;
@@ -245,6 +270,7 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     if (!h) return DVI_ESKF_ENOMEM;
     const size_t es = elem_size(src->dtype);
     h->d_noise = nullptr;             // (the struct copy aliased the source's buffers)
+    h->side_ready = false;            // (... and its streams: the copy makes its own when it needs them)
     if (!alloc_buffers(h)) {
         delete h;
         return DVI_ESKF_ENOMEM;
@@ -293,6 +319,7 @@ int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
 void dvi_eskf_destroy(dvi_eskf* h) {
     if (!h) return;
     DeviceGuard g(h->device);
+    free_side_streams(h);
     free_buffers(h);
     delete h;
 }
@@ -450,6 +477,44 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
     const char* pos = static_cast<const char*>(sc->pos);
     const char* quat = static_cast<const char*>(sc->quat_xyzw);
     const char* notch = static_cast<const char*>(sc->notch);
+    // An under-filled batch (the serial part of an epoch -- its recurrences -- leaves most of the chip idle): the two
+    // halves of the batch run their epochs on two streams, so that one half's recurrences and Jacobian kernel run
+    // next to the other half's covariance kernel.  Instances do not interact, the kernels of a half touch that half's
+    // records only: the results are the same bits.  (DVI_ESKF_EPOCH_STREAMS=0 switches it off.)
+    static const bool two_streams = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS"); return !(e && e[0] == '0'); }();
+    static const int64_t two_streams_max = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS_MAX"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
+    // (measured, config #5's schedule, us per camera frame, one stream -> two: B = 1 024 72 -> 75 fp32 / 80 -> 82 fp64; 2 048
+    //  78 -> 79 / 98 -> 86; 4 096 100 -> 83 / 115 -> 106; 8 192 129 -> 114 / 148 -> 146; 16 384 184 -> 167 / 256 -> 246)
+    static const int64_t two_streams_min = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)2048; }();
+    bool split = two_streams && eskf::epoch_sub_batches_available() && h->lpi == 1 && !h->d_noise && !sc->rows_out &&
+                 (h->B % 128) == 0 && h->B >= two_streams_min && h->B <= two_streams_max && sc->n_epochs >= 2;
+    for (int64_t e = 0; e < sc->n_epochs && split; ++e) split = sc->n_pred[e] >= 2;
+    if (split) {
+        DeviceGuard g(h->device);
+        hipStream_t cs = (hipStream_t)stream;
+        if (!g.ok || !ensure_side_streams(h)) return DVI_ESKF_EHIP;
+        if (hipEventRecord(h->ev_fork, cs) != hipSuccess) return DVI_ESKF_EHIP;
+        const int64_t half = h->B / 2;
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (hipStreamWaitEvent(h->side[s2], h->ev_fork, 0) != hipSuccess) return DVI_ESKF_EHIP;
+        size_t off2 = 0;
+        for (int64_t e = 0; e < sc->n_epochs; ++e) {        // (enqueued epoch by epoch, alternating: both queues always have work)
+            const int n = sc->n_pred[e];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                int rc = step_common(h, n, 1, dt + off2 * dt_row, sc->dt_per_instance, om + off2 * imu_row, acc + off2 * imu_row,
+                                     sc->imu_per_instance, pos + (size_t)e * mrow * 3 * es, quat + (size_t)e * mrow * 4 * es,
+                                     notch + (size_t)e * mrow * es, sc->meas_per_instance, nullptr,
+                                     sc->status ? sc->status + (size_t)e * B : nullptr, h->side[s2], nullptr, s2 * half, half);
+                if (rc != DVI_ESKF_OK) return rc;
+            }
+            off2 += (size_t)n;
+        }
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (hipEventRecord(h->ev_join[s2], h->side[s2]) != hipSuccess || hipStreamWaitEvent(cs, h->ev_join[s2], 0) != hipSuccess)
+                return DVI_ESKF_EHIP;
+        if (stream_is_capturing(cs)) h->captured = true;
+        return DVI_ESKF_OK;
+    }
     size_t off = 0;
     for (int64_t e = 0; e < sc->n_epochs; ++e) {
         const int n = sc->n_pred[e];

@@ -86,10 +86,16 @@ struct StepArgs {
     // dvi_eskf_step_from; otherwise the handle's own P / xs -- the step is then in place)
     const void* P_src;
     const void* xs_src;
+    // a launch over a PART of the batch: instances [sub_first, sub_first + sub_count), both multiples of 64 (sub_count = 0:
+    // the whole batch).  B stays the stride of every array.  Honoured by eskf_nominal_kernel, eskf_jac_kernel and the
+    // row-resident covariance kernel with 32 lanes per instance (dvi_eskf_run_epochs pipelines two halves of an
+    // under-filled batch on two streams with it).
+    int64_t sub_first, sub_count;
 };
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
+bool epoch_sub_batches_available();
 hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
                        const void* qo4, void* xs, void* Ppk, hipStream_t stream);
 hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,

@@ -1287,9 +1287,10 @@ __global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevPar
     __shared__ T sX[9 * 64];                            // s1 c1 s2 c2 s3 c3 (pre-predict dofs) | p_cam after the last predict
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x >> 6;                 // wave-uniform
-    const int64_t b_raw = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = b_raw < a.B;
-    const int64_t b = live ? b_raw : a.B - 1;          // tail lanes recompute the last instance, write nothing
+    const int64_t hi = a.sub_count ? a.sub_first + a.sub_count : a.B;       // (a launch may cover a part of the batch)
+    const int64_t b_raw = a.sub_first + (int64_t)blockIdx.x * 64 + lane;
+    const bool live = b_raw < hi;
+    const int64_t b = live ? b_raw : hi - 1;           // tail lanes recompute the last instance, write nothing
     const T* xi = reinterpret_cast<const T*>(a.xs_src);
     T* xo = reinterpret_cast<T*>(a.xs);
     T* aux = reinterpret_cast<T*>(a.aux);
@@ -1550,12 +1551,13 @@ __global__ __launch_bounds__(128, 4) void eskf_jac_kernel(StepArgs a, DevParams<
     const int lane = threadIdx.x & 63;
     const int role = threadIdx.x >> 6;
     const int64_t B = a.B;
-    const int64_t njobs = (int64_t)a.n_pred * B;
+    const int64_t cnt = a.sub_count ? a.sub_count : B;              // instances of this launch: [sub_first, sub_first + cnt)
+    const int64_t njobs = (int64_t)a.n_pred * cnt;
     const int64_t job0 = (int64_t)blockIdx.x * 64;
     const int64_t job_raw = job0 + lane;
     const int64_t job = job_raw < njobs ? job_raw : njobs - 1;      // tail lanes recompute the last job, write nothing
-    const int k = (int)(job / B);
-    const int64_t b = job - (int64_t)k * B;
+    const int k = (int)(job / cnt);
+    const int64_t b = a.sub_first + (job - (int64_t)k * cnt);
     const T* aux = reinterpret_cast<const T*>(a.aux);
     const T* ak = aux + (int64_t)(AUX0 + AUXK * k) * B + b;
     const T dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? (int64_t)k * B + b : k];
@@ -1591,7 +1593,9 @@ __global__ __launch_bounds__(128, 4) void eskf_jac_kernel(StepArgs a, DevParams<
         jac_blocks_attitude(prm, t, ak[5 * B], om_t, om_o, dt, J);
     }
     __syncthreads();
-    T* gJ = reinterpret_cast<T*>(a.J) + job0 * JW + J_B0;
+    // (the block's records are consecutive: predict-major jobs over the whole batch, or a part whose size is a multiple of 64)
+    const int64_t k0 = job0 / cnt;
+    T* gJ = reinterpret_cast<T*>(a.J) + (k0 * B + a.sub_first + (job0 - k0 * cnt)) * JW + J_B0;
     const int nrec = (njobs - job0 < 64) ? (int)(njobs - job0) : 64;
     const int first = role * 32, last = (first + 32 < nrec) ? first + 32 : nrec;
     if (prm.jfull) store_records<T, JB_FULL>(sJ, gJ, last, lane, first);
@@ -2723,7 +2727,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     // waves cover the HBM latency, and 32 768 short blocks balance better than 8 192 long ones).
     // Instance indices are 32-bit (the launcher refuses B >= 2^31) and opaque: byte addresses are
     // formed where they are used instead of being kept in registers from the prologue on.
-    const int nB = (int)a.B;
+    const int nB = (int)(a.sub_count ? a.sub_first + a.sub_count : a.B);    // (one past the last instance of this launch)
     const int slot = vblock * G + grp;
     // Jacobian record IP of instance INST and the residual of the update -> registers -> LDS.  No
     // predicates either: every lane moves three record words (the 88-word record is padded; what
@@ -3192,7 +3196,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     constexpr int G = LPI == 32 ? 2 : 8;
     constexpr int REGION = SLIM ? (PIN ? 664 : 640) : PIN ? rowk::R_REGION_PIN : rowk::R_REGION;
     __shared__ __attribute__((aligned(16))) T smem[G * REGION];
-    cov_rows_body<T, PIN, LPI, SLIM>(a, prm, smem, (int)blockIdx.x, (int)threadIdx.x);
+    cov_rows_body<T, PIN, LPI, SLIM>(a, prm, smem, (int)blockIdx.x + (int)(a.sub_first / G), (int)threadIdx.x);
 }
 
 // state.dofs of every instance (Filter.calculate_dof_metric, Filter.py:452-455; the payload of the final gather)
@@ -3498,7 +3502,8 @@ template <typename T, bool PIN = false, int LPI = 32>
 static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = LPI == 32 ? 2 : 8;                    // instances per block
     if (a.B >= 0x7fffffffLL) return hipErrorInvalidValue;   // 32-bit instance indices in the kernel
-    const int64_t blocks = (a.B + G - 1) / G;
+    if (a.sub_count && LPI != 32) return hipErrorInvalidValue;
+    const int64_t blocks = ((a.sub_count ? a.sub_count : a.B) + G - 1) / G;
     if constexpr (LPI == 32) {
         if (!prm.q_gyro) {      // no gyro block in Q (the normal case): the four-waves-per-SIMD build of the same kernel
             hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, 32, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
@@ -3518,6 +3523,9 @@ static const int64_t g_epoch_split_max = []() { const char* e = getenv("DVI_ESKF
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
+    // a part of the batch: only the kernels that honour sub_first / sub_count (the host asks for it under these conditions only)
+    if (a.sub_count && (a.n_pred < 2 || g_pre_legacy || !a.aux || a.noise || a.K_out || lpi != 1 || (a.sub_count & 63) || (a.sub_first & 63)))
+        return hipErrorInvalidValue;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? JB_FULL : JB_CORE) + 9) * sizeof(T);    // + parked measurement
     if (a.n_pred == 1 && !g_pre_legacy) {
@@ -3529,18 +3537,19 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
         hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
     } else if (a.n_pred == 1)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
-    else if (a.n_pred >= 2 && !g_pre_legacy && a.aux && (a.B <= g_epoch_split_max || g_epoch_split_max < 0)) {
+    else if (a.n_pred >= 2 && !g_pre_legacy && a.aux && (a.B <= g_epoch_split_max || g_epoch_split_max < 0 || a.sub_count)) {
         // epochs: the recurrences, then the Jacobian blocks of all predicts at once.  Pays while the batch under-fills
         // the chip for a lane-per-instance kernel (measured, epoch time against the two-role kernel below, fp64 / fp32,
         // 10 and 33 predicts: B = 1 024 x0.50-0.71, 8 192 x0.70-0.81, 16 384 x0.83-0.93, 32 768 x0.97-1.02, 65 536
         // x1.02-1.05: there 1 024 blocks fill every CU, the serial loop is no longer exposed, and the extra launch and
         // the hand-over words cost more than they save)
-        const dim3 gb((unsigned)((a.B + 63) / 64));
+        const int64_t cnt = a.sub_count ? a.sub_count : a.B;
+        const dim3 gb((unsigned)((cnt + 63) / 64));
         if (!a.imu_stride && !a.dt_stride) hipLaunchKernelGGL((eskf_nominal_kernel<T, true>), gb, dim3(128), 0, stream, a, prm);
         else hipLaunchKernelGGL((eskf_nominal_kernel<T, false>), gb, dim3(128), 0, stream, a, prm);
         hipError_t e0 = hipGetLastError();
         if (e0 != hipSuccess) return e0;
-        const int64_t njobs = (int64_t)a.n_pred * a.B;
+        const int64_t njobs = (int64_t)a.n_pred * cnt;
         if ((njobs + 63) / 64 > 0x7fffffffLL) return hipErrorInvalidValue;
         const size_t jl = (size_t)64 * (prm.jfull ? JB_FULL : JB_CORE) * sizeof(T);
         hipLaunchKernelGGL((eskf_jac_kernel<T>), dim3((unsigned)((njobs + 63) / 64)), dim3(128), jl, stream, a, prm);
@@ -3582,6 +3591,9 @@ static hipError_t launch_flush_typed(const StepArgs& a, const DevParams<T>& prm,
     hipLaunchKernelGGL(eskf_post_kernel<T>, dim3((unsigned)((a.B + 255) / 256)), dim3(256), 0, stream, a, prm);
     return hipGetLastError();
 }
+
+// whether launches over a part of the batch are available for epochs (see StepArgs::sub_first)
+bool epoch_sub_batches_available() { return !g_pre_legacy; }
 
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
     if (dtype == 0) return launch_flush_typed<double>(a, make_dev_params<double>(hp), stream);

@@ -188,6 +188,11 @@ typedef struct dvi_eskf_schedule {
     void* rows_out;         /* NULL or device [n_epochs,B,30]: dvi_eskf_log_rows after every update
                                (Filter.update appends to the trajectory log, Filter.py:394)       */
 } dvi_eskf_schedule;
+/* For an under-filled batch (2 048 <= B <= 16 384, B a multiple of 128, every epoch with at least two predicts, no
+ * log rows, shared noise model, default covariance kernel) the two halves of the batch are enqueued on two streams
+ * of the handle's own, forked from and joined to `stream` by events: one half's recurrences and Jacobian kernel
+ * then run next to the other half's covariance kernel.  Instances do not interact: the results are bit for bit those
+ * of the one-stream order, and the call stays capturable. */
 int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sched, void* stream);
 
 /* The estimated calibration parameters, i.e. state.dofs (Filter.calculate_dof_metric,

@@ -225,3 +225,69 @@ def test_step_from_a_snapshot_equals_copy_then_step(lpi):
     L = _capi.lib()
     assert L.dvi_eskf_step_from(a._h, other._h, 1, None, 0, None, None, 0, None, None, None, 0, None, None, None) == -1
     assert L.dvi_eskf_step_from(a._h, None, 1, None, 0, None, None, 0, None, None, None, 0, None, None, None) == -1
+
+
+@pytest.mark.parametrize("dtype,per_instance", [("float64", False), ("float64", True), ("float32", False)])
+def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance):
+    """An under-filled batch (B a multiple of 128, 2 048 <= B <= 16 384, every epoch with >= 2 predicts, no log rows):
+    dvi_eskf_run_epochs runs the two halves of the batch on two streams of the handle's own -- one half's recurrences
+    and Jacobian kernel next to the other half's covariance kernel.  Same bits as the epochs called one by one (which
+    cover the whole batch per launch), status words included; also when the call is captured into a HIP graph."""
+    from tests.helpers import default_run
+    from dvi_ekf_amd.batch import BatchedESKF
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False)
+    B = 2176                                                    # 17 x 128: halves of 1 088 = 17 groups of 64
+    dt_ = getattr(torch, dtype)
+    f = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so,
+                    hold_frozen=False, dtype=dt_)
+    f.set_noise(Q, R)
+    rng = np.random.default_rng(17)
+    x0 = np.tile(ri.x0, (B, 1))
+    x0[:, 10:13] += rng.normal(0, 0.02, (B, 3))
+    x0[:, 13:16] += rng.normal(0, 2.0, (B, 3))
+    x0[:, 17] = rng.normal(0, 0.05, B)                         # moving notch: the trigonometry of phi changes per predict
+    f.set_state(x=x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    n_pred = np.array([10, 3, 17, 2, 10], dtype=np.int32)
+    E, total = len(n_pred), int(n_pred.sum())
+    pos = ri.pos[:E, None, :] + rng.normal(0, 1e-3, (E, B, 3))
+    quat = np.repeat(ri.quat[:E, None, :], B, axis=1)
+    notch = rng.normal(0, 1e-3, (E, B))
+    if per_instance:
+        dt = np.repeat(ri.dt[:total, None], B, axis=1) * rng.uniform(0.9, 1.1, (total, B))
+        om = ri.om[:total, None, :] + rng.normal(0, 1e-3, (total, B, 3))
+        acc = ri.acc[:total, None, :] + rng.normal(0, 1e-2, (total, B, 3))
+    else:
+        dt, om, acc = ri.dt[:total], ri.om[:total], ri.acc[:total]
+    f.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])        # (an injection is pending at the start)
+    g, c = f.clone(), f.clone()
+    g.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])
+    c.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])
+    f.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])
+    status, _ = f.run_epochs(n_pred, dt, om, acc, pos, quat, notch)
+    off = 0
+    for e in range(E):
+        n = int(n_pred[e])
+        st, _ = g.epoch(dt[off:off + n], om[off:off + n], acc[off:off + n], pos[e], quat[e], notch[e])
+        off += n
+        assert torch.equal(status[e], st)
+    sf, sg = f.get_state(), g.get_state()
+    for key in sf:
+        assert torch.equal(sf[key], sg[key]), key
+    assert bool(torch.isfinite(sf["x"]).all())
+    # captured: the side streams join the capture through the fork / join events
+    dev = f.device
+    dev_t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dt_, device=dev)
+    tdt, tom, tacc, tpos, tquat, tnotch = dev_t(dt), dev_t(om), dev_t(acc), dev_t(pos), dev_t(quat), dev_t(notch)
+    c.reserve(int(n_pred.max()))
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize(dev)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side):
+        c.run_epochs(n_pred, tdt, tom, tacc, tpos, tquat, tnotch)
+    torch.cuda.synchronize(dev)
+    gr.replay()
+    torch.cuda.synchronize(dev)
+    sc_ = c.get_state()
+    for key in sf:
+        assert torch.equal(sf[key], sc_[key]), ("captured", key)
