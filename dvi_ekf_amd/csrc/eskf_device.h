@@ -26,7 +26,7 @@ struct DevParams {
     int frozen_mask;    // bit i: DOF i frozen
     int hold_frozen;    // 0: zero frozen DOFs after predict (Filter.py:243-245); 1: hold
     int q_gyro;         // diag(Q)[3:6] has a non-zero entry
-    int jfull;          // the pre kernel writes 85-word Jacobian records (with the N6 block): q_gyro, or the
+    int jfull;          // the pre kernels write all 85 block words of a record (with the N6 block): q_gyro, or the
                         // handle keeps the Jacobians for dvi_eskf_get_jacobians
 };
 
@@ -111,7 +111,7 @@ hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void*
 hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double* cam6, const double* imu6, void* mse,
                              hipStream_t stream);
 
-// Fx [B,24,24] and Fi [B,24,13] of the predict whose (full, 85-word) record is J[ip]
+// Fx [B,24,24] and Fi [B,24,13] of the predict whose full record (85 block words) is J[ip]
 hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, hipStream_t stream);
 
 // eskf_noise.hip -- kind: 0 = normals f64, 1 = normals f32, 2 = raw Philox words (uint32 x 4 per triple)

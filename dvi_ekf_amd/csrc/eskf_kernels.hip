@@ -6,8 +6,9 @@
 // probe forward kinematics (models/Probe.py:147-167,431-480), in closed form
 // (SURVEY.md App. A/B).
 //
-// One predict(+update) step = eskf_pre_kernel (lane per instance: nominal state, Jacobian blocks,
-// residual) -> eskf_cov_rows_kernel (32 lanes per instance, rows of P in registers: covariance
+// One predict(+update) step = a pre kernel (lane per instance: nominal state, Jacobian blocks, residual --
+// eskf_pre4_kernel for launches with one predict, eskf_nominal_kernel + eskf_jac_kernel for epochs of an under-filled
+// batch, eskf_pre_kernel otherwise) -> eskf_cov_rows_kernel (32 lanes per instance, rows of P in registers: covariance
 // propagation, the measurements one after the other, reset; eskf_cov_kernel<LPI> is the same step
 // on an LDS image of P and also forms the gain matrix) ; the error injection of an update is applied
 // by the next step's pre kernel or, when the state is read in between, by eskf_post_kernel.  See
@@ -18,7 +19,8 @@
 //                of 25 words, word c of double row r is P[r][c] for c <= r, else P[23-r][c-r-1]
 //   xs [36][B]   structure-of-arrays state: words x26 | om_old3 | acc_old3 | q_old4
 //                (R_WB_old = Rm(q_old), Filter.py:227)
-//   J  [n][B][88], res [B][8], e [B][24], status [B]   workspace between the kernels
+//   J  [n][B][96]  records between the kernels: residual of the launch's update (8 words, first predict's record) |
+//                  Jacobian blocks (67 words; 85 with N6); e [B][24], status [B]; aux [12 + 8 n][B] (epochs)
 //                (status bit 30 = "this instance's error state still awaits its injection": device state,
 //                 so that captured step sequences replay correctly -- see eskf_pre_kernel)
 #include <hip/hip_runtime.h>
@@ -609,7 +611,7 @@ template <typename T, bool ONE, bool SIMU = false>
 __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<T> prm) {
     // Two wavefronts per block work on the same 64 instances: wave 0 propagates the nominal state
     // (and forms the residual), wave 1 forms the Jacobian blocks.  Both read the state before wave 0
-    // overwrites it (block barrier).  Wave 1 stages its 67-word records in LDS (row stride 69:
+    // overwrites it (block barrier).  Wave 1 stages the 67 block words of its records in LDS (odd row stride:
     // conflict-free) and writes them out as whole records with 16-byte stores -- a lane-per-instance
     // store of an array-of-structures would touch 64 different cache lines per instruction.
     static_assert(sizeof(Jac<T>) == JB_FULL * sizeof(T), "Jac<T> must be the 85 block words of the record");
@@ -2730,7 +2732,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     const int nB = (int)(a.sub_count ? a.sub_first + a.sub_count : a.B);    // (one past the last instance of this launch)
     const int slot = vblock * G + grp;
     // Jacobian record IP of instance INST and the residual of the update -> registers -> LDS.  No
-    // predicates either: every lane moves three record words (the 88-word record is padded; what
+    // predicates either: every lane moves three record words (the 96-word record is padded; what
     // lies beyond the blocks in use lands in the idle N6 area) and one residual word.
 #define ESKF_LOAD_J(DST, RES, INST, IP)                                                            \
     {                                                                                              \
@@ -3429,7 +3431,7 @@ __global__ __launch_bounds__(256) void eskf_update_mse_kernel(int64_t B, const T
 
 // ----------------------------------------------------------------------------------
 // Filter.Fx / Filter.Fi (Filter.py:249-268,279-285): the dense matrices of one predict, materialised
-// from its (full, 85-word) Jacobian record -- the kernels themselves never form them.  One thread per
+// from its full record (85 block words) -- the kernels themselves never form them.  One thread per
 // (instance, row).  Layout of the camera rows incl. the reference's column cursor (SURVEY.md App. A.3,
 // Q1): row 18+r: dt at col 3+r | Bm[r] at 6:9 | Cm[r] at 9:15 | 1 at col 16+r; row 21+r: Dm[r][0:3] at
 // 9:12 | Dm[r][3] at col 15 | Em[r] at 19:22 | the 1 of I_24 that survives at (22,22), (23,23).
