@@ -1,5 +1,5 @@
 #!/bin/bash
-# (GPU box) the looping covariance kernel against the one-pair-per-wave kernel, bit for bit, on the scenarios of
+# (GPU box; for a build with profiles/r03_cov_loop_experiment.patch applied) the looping covariance kernel against the one-pair-per-wave kernel, bit for bit, on the scenarios of
 # tests/_pre4_child.py:  tools/check_loop.sh <rounds> [scenario ...]
 r=$1; shift
 for sc in "${@:-unfrozen}"; do
