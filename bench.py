@@ -423,11 +423,35 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch") if B == 65536 else None     # (measured at the headline batch)
                 traffic_source = ("static: profiles/traffic_per_launch.json -- a constant taken from the committed rocprofv3 "
                                   "PMC pass of this kernel pair (FETCH_SIZE x2 + WRITE_SIZE per step), NOT measured in this run")
             except Exception:
                 traffic = None
+        # A yardstick next to the 8 TB/s figure: the rate at which this box copies a buffer of the step's own measured
+        # traffic (half read, half written) -- what its memory system gives the simplest kernel with the same mix.
+        yardstick = None
+        if traffic and world == 1 and not args.no_streaming:
+            try:
+                n8 = int(traffic) // 16
+                src = torch.empty(n8, dtype=torch.float64, device=dev).normal_()
+                dst = torch.empty_like(src)
+                for _ in range(5):
+                    dst.copy_(src)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(100):
+                    dst.copy_(src)
+                c1.record()
+                torch.cuda.synchronize(dev)
+                copy_gbs = 16.0 * n8 * 100 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+                step_gbs = float(traffic) / (kern_ms * 1e-3) / 1e9
+                yardstick = {"copy_GBps": copy_gbs, "step_traffic_GBps": step_gbs, "step_over_copy": step_gbs / copy_gbs,
+                             "note": "device-to-device copy of traffic/2 bytes (read + write counted), measured in this run; "
+                                     "step_traffic = roofline.traffic / kernel_ms"}
+                del src, dst
+            except Exception as ex:     # (never the reason a bench line is missing)
+                yardstick = {"error": repr(ex)}
         out = {
             "metric": "ESKF predict+update steps/sec, 26-state, batch=65536 at 1/2/4/8 MI355X",
             "value": value,
@@ -463,12 +487,13 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_wall": achieved_wall / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "one step = eskf_pre_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes)",
+                "kernel": "one step = eskf_pre4_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes)",
                 "timing": "frac: HIP events on the launch stream around the K steps of the timed region; frac_wall: from "
                           "ms_per_step (host clock, includes the final calibration read, the synchronisation and barriers)",
                 "kernel_ms": kern_ms, "kernel_ms_eager_launches": kern_ms_eager,
                 "algorithmic_bytes_per_launch": BYTES_PER_PAIR_F64 * B,
                 "streaming": streaming,
+                "copy_yardstick": yardstick,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
