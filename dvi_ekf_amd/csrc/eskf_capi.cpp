@@ -310,8 +310,8 @@ int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
     if ((dst->maybe_pending || dst->captured) &&
         hipMemsetAsync(dst->d_status, 0, (size_t)dst->B * sizeof(int32_t), s) != hipSuccess) return DVI_ESKF_EHIP;
     dst->maybe_pending = false;
-    if (hipMemcpyAsync(dst->d_P, src->d_P, (size_t)src->B * 300 * es, hipMemcpyDeviceToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(dst->d_x, src->d_x, (size_t)src->B * 36 * es, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (dst == src) return DVI_ESKF_OK;
+    if (eskf::launch_copy_state(src->d_P, dst->d_P, (size_t)src->B * 300 * es, src->d_x, dst->d_x, (size_t)src->B * 36 * es, s) != hipSuccess)
         return DVI_ESKF_EHIP;
     return DVI_ESKF_OK;
 }

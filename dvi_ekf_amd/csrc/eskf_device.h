@@ -96,6 +96,7 @@ struct StepArgs {
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 bool epoch_sub_batches_available();
+hipError_t launch_copy_state(const void* srcP, void* dstP, size_t bytesP, const void* srcx, void* dstx, size_t bytesx, hipStream_t stream);
 hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
                        const void* qo4, void* xs, void* Ppk, hipStream_t stream);
 hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, void* x26, void* P576, void* om3,

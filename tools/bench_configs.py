@@ -45,8 +45,14 @@ def config3(B):
             "frac_of_8TBps": B * bytes_per / t / 8e12, "finite": ok}
 
 
-def epoch10(B=65536, N=10):
-    from dvi_ekf_amd.workloads import monte_carlo_pairs
+def epoch10(B=65536, N=10, epochs=32):
+    """The reference's own schedule -- ten predicts (dt = 0.1) and one update per epoch, one launch sequence per
+    epoch -- on the Monte-Carlo batch (unfrozen DOFs, per-instance IMU and camera streams).  The state is restored
+    from a snapshot BEFORE the timed region and stays finite for its 32 epochs (checked); rounds 1-2 restored every
+    four epochs inside it, and that device-to-device copy (dvi_eskf_copy_state, ~0.26 ms at this batch) was a
+    sixth of the figure.  Second entry: the same ratio as a real run -- camera at 30 Hz, IMU at 300 Hz on the
+    smooth_traj path (dvi_ekf_amd.workloads.long_horizon), 40 epochs enqueued by ONE dvi_eskf_run_epochs call."""
+    from dvi_ekf_amd.workloads import long_horizon, monte_carlo_pairs
     dev = torch.device("cuda:0")
     wl = monte_carlo_pairs(B, horizon=4, seed=4, device=dev)
     f = wl.make_filter()
@@ -54,19 +60,49 @@ def epoch10(B=65536, N=10):
     dt = torch.full((N,), 0.1, device=dev, dtype=torch.float64)
     om = wl.om[0].unsqueeze(0).repeat(N, 1, 1).contiguous()
     acc = wl.acc[0].unsqueeze(0).repeat(N, 1, 1).contiguous()
-    k = [0]
-
-    def step():
-        if k[0] % 4 == 0:
-            f.copy_state_from(snap)
-        f.epoch(dt, om, acc, wl.pos[k[0] % 4], wl.quat[k[0] % 4], wl.notch[k[0] % 4])
-        k[0] += 1
-
-    t = _time(step, 32, warm=4)
+    best = None
+    for _ in range(3):
+        f.copy_state_from(snap)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for k in range(epochs):
+            f.epoch(dt, om, acc, wl.pos[k % 4], wl.quat[k % 4], wl.notch[k % 4])
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / epochs
+        best = t if best is None else min(best, t)
+    t = best
+    finite = bool(torch.isfinite(f.x).all())
     bytes_per = 5440 + 56 * N
-    return {"config": "v1-literal 10:1 epochs, fp64", "batch": B, "n_pred": N, "ms_per_epoch": t * 1e3, "value": B / t,
+    out = [{"config": "v1-literal 10:1 epochs, fp64", "batch": B, "n_pred": N, "ms_per_epoch": t * 1e3, "value": B / t,
             "unit": "epochs/s", "predict_steps_per_s": B * N / t, "algorithmic_GBps": B * bytes_per / t / 1e9,
-            "frac_of_8TBps": B * bytes_per / t / 8e12, "state_restore_every": 4}
+            "frac_of_8TBps": B * bytes_per / t / 8e12, "epochs_timed": epochs, "state_restore_in_timed_region": False,
+            "finite": finite}]
+    del f, snap, wl
+    wl = long_horizon(batch=B, n_steps=400, imu_hz=300.0, cam_hz=30.0, frozen=(0,) * 6)
+    om, acc = wl.synthesize_imu_on_device(dtype=torch.float64, device=dev)
+    om, acc = om[1:].contiguous(), acc[1:].contiguous()
+    tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    dts, pos, quat, notch = tt(wl.dt), tt(wl.pos), tt(wl.quat), tt(wl.notch)
+    f = wl.make_filter(dtype=torch.float64, device=dev)
+    snap = f.clone()
+    times = []
+    for _ in range(4):
+        f.copy_state_from(snap)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st, _ = f.run_epochs(wl.n_pred, dts, om, acc, pos, quat, notch)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1) * 1e-3)
+    t2 = min(times[1:]) / len(wl.n_pred)
+    out.append({"config": "10:1 as a run: camera 30 Hz / IMU 300 Hz on the smooth_traj path, unfrozen DOFs, one run_epochs call, fp64",
+                "batch": B, "n_pred": sorted(set(int(n) for n in wl.n_pred)), "epochs": int(len(wl.n_pred)), "ms_per_epoch": t2 * 1e3,
+                "predict_steps_per_s": B * wl.n_steps / (t2 * len(wl.n_pred)), "skipped_updates": int((st & 1).sum()),
+                "finite": bool(torch.isfinite(f.x).all())})
+    return out
 
 
 def config5(B=8192, reps=3):
@@ -128,7 +164,8 @@ if __name__ == "__main__":
     if "config3" in what:
         print(json.dumps(config3(B3)))
     if "epoch10" in what:
-        print(json.dumps(epoch10()))
+        for r in epoch10():
+            print(json.dumps(r))
     if "config5" in what:
         for r in config5():
             print(json.dumps(r))
