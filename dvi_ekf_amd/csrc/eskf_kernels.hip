@@ -2738,10 +2738,24 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     {                                                                                              \
         int lj_ = lig;                                                                             \
         asm volatile("" : "+v"(lj_));   /* (per-lane addresses formed here, not kept across rounds) */ \
+        if constexpr (LPI == 32) {                                                                 \
+            /* wave-uniform base + unsigned 32-bit lane offset, as for the rows; only the third word of a lane can lie \
+               in the padding of the record (words >= 64 + lane), which is not fetched */                      \
+            const int i0_ = vblock * G;                                                            \
+            const char* gJw_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + i0_) * JW); \
+            const unsigned jo_ = (unsigned)((INST) - i0_) * (unsigned)(JW * sizeof(T));            \
+            const unsigned lo_ = jo_ + (unsigned)lj_ * (unsigned)sizeof(T);                        \
+            static_assert(NJ == 3 && J_CORE - 1 >= 64, "three words per lane, the first two never padding"); \
+            DST[0] = ESKF_LDJ(reinterpret_cast<const T*>(gJw_ + (size_t)lo_));                      \
+            DST[1] = ESKF_LDJ(reinterpret_cast<const T*>(gJw_ + (size_t)lo_ + (size_t)(32 * sizeof(T)))); \
+            const int w2_ = lj_ + 64;                                                              \
+            DST[2] = ESKF_LDJ(reinterpret_cast<const T*>(gJw_ + (size_t)(jo_ + (unsigned)(w2_ < jlast ? w2_ : jlast) * (unsigned)sizeof(T)))); \
+        } else {                                                                                   \
         const T* gJ_ = reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + (INST)) * JW;      \
         _Pragma("unroll") for (int k = 0; k < NJ; ++k) {                                           \
-            const int w_ = LPI == 32 ? lj_ + 32 * k : kRowsTables.jsrc[TV][lj_][k];   /* (same numbers) */ \
+            const int w_ = kRowsTables.jsrc[TV][lj_][k];                                           \
             DST[k] = ESKF_LDJ(gJ_ + (w_ < jlast ? w_ : jlast));   /* (the padding of the record is not fetched) */ \
+        }                                                                                          \
         }                                                                                          \
         /* (32 lanes per instance: the residual is words 0..7 of the first record, i.e. already in DST[0]) */ \
         if constexpr (LPI != 32) RES.x = (reinterpret_cast<const T*>(a.J) + (int64_t)(INST) * JW + J_RES)[lj_ & 7]; \
@@ -2790,8 +2804,13 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
                 /* (j <= row) ? va + 8 j : vb + c_j  as  select(vb + (c_j - 8 j), va) + 8 j: which lanes hold a     \
                    row >= j is a CONSTANT of the lane layout -- handed to the select as a scalar mask, no       \
                    compare; the + 8 j rides in the load's offset field */                                      \
-                const unsigned o_ = rowk::select_lanes_ge<LPI == 32>(j, va_, vb_ + (cj_ - 8u * (unsigned)j), rw_) + 8u * (unsigned)j; \
-                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
+                /* The common part m_j = min(8 j, c_j) of the two alternatives is added AFTER the zero extension of the  \
+                   lane offset, where the compiler can move it into the load's offset field (a 32-bit sum could wrap,    \
+                   so it would not); what remains on either side is non-negative, so nothing wraps before it. */        \
+                const unsigned e8_ = 8u * (unsigned)j;                                                               \
+                const unsigned mj_ = cj_ < e8_ ? cj_ : e8_;                                                          \
+                const unsigned o_ = rowk::select_lanes_ge<LPI == 32>(j, va_ + (e8_ - mj_), vb_ + (cj_ - mj_), rw_);   \
+                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_ + (size_t)mj_);   \
             }                                                                                      \
     }
 #define ESKF_UNPACK_ROW()                                                                          \
@@ -2815,8 +2834,13 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
                 /* (j <= row) ? va + 8 j : vb + c_j  as  select(vb + (c_j - 8 j), va) + 8 j: which lanes hold a     \
                    row >= j is a CONSTANT of the lane layout -- handed to the select as a scalar mask, no       \
                    compare; the + 8 j rides in the load's offset field */                                      \
-                const unsigned o_ = rowk::select_lanes_ge<LPI == 32>(j, va_, vb_ + (cj_ - 8u * (unsigned)j), rw_) + 8u * (unsigned)j; \
-                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_); \
+                /* The common part m_j = min(8 j, c_j) of the two alternatives is added AFTER the zero extension of the  \
+                   lane offset, where the compiler can move it into the load's offset field (a 32-bit sum could wrap,    \
+                   so it would not); what remains on either side is non-negative, so nothing wraps before it. */        \
+                const unsigned e8_ = 8u * (unsigned)j;                                                               \
+                const unsigned mj_ = cj_ < e8_ ? cj_ : e8_;                                                          \
+                const unsigned o_ = rowk::select_lanes_ge<LPI == 32>(j, va_ + (e8_ - mj_), vb_ + (cj_ - mj_), rw_);   \
+                p[j] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(gPw_) + (size_t)o_ + (size_t)mj_);   \
             }                                                                                      \
             gsync();   /* (the staged Jacobian record and residual are visible to every lane) */ \
         } else {                                                                                   \
