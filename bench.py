@@ -458,6 +458,21 @@ def main():
                              "note": "device-to-device copy of traffic/2 bytes (read + write counted), measured in this run; "
                                      "step_traffic = roofline.traffic / kernel_ms"}
                 del src, dst
+                if streaming:       # the same comparison at the streaming batch (traffic scaled with the batch)
+                    ns = int(traffic * streaming["batch"] / B) // 16
+                    src = torch.empty(ns, dtype=torch.float64, device=dev).normal_()
+                    dst = torch.empty_like(src)
+                    for _ in range(2):
+                        dst.copy_(src)
+                    c0.record()
+                    for _ in range(20):
+                        dst.copy_(src)
+                    c1.record()
+                    torch.cuda.synchronize(dev)
+                    sc = 16.0 * ns * 20 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+                    st = float(traffic) * streaming["batch"] / B / (streaming["kernel_ms"] * 1e-3) / 1e9
+                    yardstick.update({"streaming_copy_GBps": sc, "streaming_step_traffic_GBps": st, "streaming_step_over_copy": st / sc})
+                    del src, dst
             except Exception as ex:     # (never the reason a bench line is missing)
                 yardstick = {"error": repr(ex)}
         out = {
