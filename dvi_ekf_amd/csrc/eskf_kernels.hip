@@ -2418,6 +2418,18 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
                  : : "memory");
 }
 
+// lanes whose value is zero, an infinity or a NaN -- v_cmp_class with the result in scalar registers
+__device__ __forceinline__ unsigned long long unusable_pivot_mask(double v) {
+    unsigned long long m;
+    asm("v_cmp_class_f64_e64 %0, %1, %2" : "=s"(m) : "v"(v), "v"(0x267));     // sNaN qNaN -inf -0 +0 +inf
+    return m;
+}
+__device__ __forceinline__ unsigned long long unusable_pivot_mask(float v) {
+    unsigned long long m;
+    asm("v_cmp_class_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v), "v"(0x267));
+    return m;
+}
+
 // ---- cross-lane broadcast without LDS (32 lanes per instance; fp64 shown, fp32 below) --------------
 // An instance occupies two 16-lane DPP rows: rows 0..15 of P in the first, rows 16..23 (+ 8 shadow
 // lanes) in the second.  `row_newbcast:n` feeds lane n of the reader's own 16-lane row to every lane
@@ -2429,9 +2441,12 @@ __device__ __forceinline__ void pin_row(T (&p)[24]) {
 //  swap's row pairing -- and that it needs its wait states --, v_fmac_f64_dpp issuing at the rate of
 //  v_fmac_f64.)
 __device__ __forceinline__ void spread_rows(double v, double& X, double& Y) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    // (two 64-bit copies of v made first and consumed in place by the swaps: v_mov_b64 x 2 instead of the four
+    //  v_mov_b32 the compiler emits when it has to duplicate the halves of a value that stays live)
+    double c0 = v, c1 = v;
+    asm("" : "+v"(c0), "+v"(c1));
+    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(c0), __double2loint(c1), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(c0), __double2hiint(c1), false, false);
     X = __hiloint2double(b[0], a[0]);
     Y = __hiloint2double(b[1], a[1]);
     // A DPP read needs 2 wait states after a VALU write of its source, and inline assembly is opaque to
@@ -2995,6 +3010,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         }
         int napplied = 0;
         unsigned long long okm[7] = {0, 0, 0, 0, 0, 0, 0};  // (DPPU) lanes whose instance has applied measurement m
+        unsigned long long failm = 0;                       // (DPPU) lanes whose update has met an unusable pivot
         // 32 lanes per instance: the column every lane needs is handed around as DPP operands
         // (no LDS read-back, no barrier); the LDS copy is only written, for the take-back below
         constexpr int CS = DPPU ? 32 : 24;  // stride of the published columns (DPPU: every lane writes, no predicate)
@@ -3008,9 +3024,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
                 spread_rows(pm, X, Y);
                 const T csel = dpp_bcast<(sm & 15)>(sm < 16 ? X : Y);
                 const T sv = csel + (PIN ? sN[13 + m] : prm.r[m]);
-                fail = fail || !(sv != T(0) && t_finite(sv));
-                okm[m] = __builtin_amdgcn_ballot_w64(!fail);    // (a scalar copy of the branch mask: the take-back reads it)
-                if (!fail) {
+                // lanes whose pivot is zero or non-finite, as a scalar mask straight from the class compare and kept
+                // as one: a `bool fail` carried through these branches is turned into a register and back by the
+                // compiler at every measurement
+                failm |= unusable_pivot_mask(sv);
+                okm[m] = ~failm;                                // (the take-back reads it)
+                if (!__builtin_amdgcn_inverse_ballot_w64(failm)) {
                     const T g = fast_rcp(sv);
                     const T rm = dpp_bcast<m>(Xres);
                     const T tau = (m == 0) ? rm * g : (rm - E[m]) * g;      // (E starts at zero: nothing to subtract yet)
@@ -3034,6 +3053,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
                 pin_row(p);
                 asm volatile("" : "+v"(e), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
             });
+            fail = __builtin_amdgcn_inverse_ballot_w64(failm);
             if (__builtin_expect(fail, 0)) gsync();   // (the published columns are read below)
         } else {
 #pragma unroll
