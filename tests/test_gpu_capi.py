@@ -227,6 +227,50 @@ def test_step_from_a_snapshot_equals_copy_then_step(lpi):
     assert L.dvi_eskf_step_from(a._h, None, 1, None, 0, None, None, 0, None, None, None, 0, None, None, None) == -1
 
 
+@pytest.mark.parametrize("dtype,B", [("float64", 1), ("float64", 1003), ("float32", 515)])
+def test_copy_state_is_a_bitwise_restore(dtype, B):
+    """dvi_eskf_copy_state (one launch of 16-byte moves over the packed covariance and the state record): the target
+    holds the source's state bit for bit, whatever it held and whatever was pending on either side; the source is
+    untouched; a copy onto itself changes nothing; handles of another batch size or dtype are refused."""
+    from dvi_ekf_amd import _capi
+    from dvi_ekf_amd.batch import BatchedESKF
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True)
+    dt_ = getattr(torch, dtype)
+    rng = np.random.default_rng(B)
+
+    def make(n=B, d=dt_):
+        f = BatchedESKF(n, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=cfg.frozen_dofs, sigma_a=sa,
+                        sigma_om=so, hold_frozen=False, dtype=d)
+        f.set_noise(Q, R)
+        f.set_state(x=np.tile(ri.x0, (n, 1)) + 1e-3 * rng.standard_normal((n, 26)), P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+        return f
+
+    src, dst = make(), make()
+    src.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])      # src: an injection pending
+    dst.step(ri.dt[1], ri.om[1], ri.acc[1], ri.pos[1], ri.quat[1], ri.notch[1])      # dst: another one, to be dropped
+    dst.step(ri.dt[2], ri.om[2], ri.acc[2], ri.pos[2], ri.quat[2], ri.notch[2])
+    want = {k: v.clone() for k, v in src.clone().get_state().items()}
+    dst.copy_state_from(src)
+    got, kept = dst.get_state(), src.get_state()
+    for key in want:
+        assert torch.equal(got[key], want[key]), key
+        assert torch.equal(kept[key], want[key]), key
+    dst.copy_state_from(dst)                                                         # onto itself
+    for key, v in dst.get_state().items():
+        assert torch.equal(v, want[key]), key
+    # ... and the copy behaves like the original from here on
+    st_a, _ = src.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[3], ri.quat[3], ri.notch[3])
+    st_b, _ = dst.step(ri.dt[3], ri.om[3], ri.acc[3], ri.pos[3], ri.quat[3], ri.notch[3])
+    assert torch.equal(st_a, st_b)
+    sa_, sb_ = src.get_state(), dst.get_state()
+    for key in sa_:
+        assert torch.equal(sa_[key], sb_[key]), key
+    L = _capi.lib()
+    assert L.dvi_eskf_copy_state(dst._h, make(B + 1)._h, None) == -1
+    assert L.dvi_eskf_copy_state(dst._h, make(B, torch.float32 if dt_ == torch.float64 else torch.float64)._h, None) == -1
+    assert L.dvi_eskf_copy_state(dst._h, None, None) == -1
+
+
 @pytest.mark.parametrize("dtype,per_instance", [("float64", False), ("float64", True), ("float32", False)])
 def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance):
     """An under-filled batch (B a multiple of 128, 2 048 <= B <= 16 384, every epoch with >= 2 predicts, no log rows):
