@@ -2699,6 +2699,9 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
+#ifndef ESKF_PACKED_IMAGE
+#define ESKF_PACKED_IMAGE 1
+#endif
 #ifdef ESKF_X_NT_JLOADS     // experiment: records are read exactly once
 #define ESKF_LDJ(p) __builtin_nontemporal_load(p)
 #else
@@ -2982,10 +2985,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     // image positions of the packed-record words this lane will store, fetched now (table in memory): asked
     // for at the point of use they cost every wavefront an exposed round trip right before its stores
     int off[PW * NV];
+    if constexpr (!(LPI == 32 && ESKF_PACKED_IMAGE)) {      // (32 lanes per instance: the store needs no positions, see there)
 #pragma unroll
-    for (int k = 0; k < PW * NV; ++k) off[k] = piece_pos(k);
+        for (int k = 0; k < PW * NV; ++k) off[k] = piece_pos(k);
 #pragma unroll
-    for (int k = 0; k < PW * NV; ++k) asm volatile("" : "+v"(off[k]));
+        for (int k = 0; k < PW * NV; ++k) asm volatile("" : "+v"(off[k]));
+    }
 
 #ifdef ESKF_X_STAMPS
     pin_row(p);
@@ -3123,7 +3128,16 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         constexpr bool DPPR = LPI == 32;    // the six attitude components of the error state reach every lane as DPP operands
         if (upd && active) {
             if constexpr (!DPPR) sC[row] = e;
-            if (valid) reinterpret_cast<T*>(a.e)[(int64_t)inst * 24 + row] = e;
+            if (valid) {
+                if constexpr (LPI == 32) {      // (wave-uniform base + 32-bit lane offset)
+                    const int i0_ = vblock * G;
+                    char* gE_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.e) + (int64_t)i0_ * 24);
+                    const unsigned eo_ = ((unsigned)(inst - i0_) * 24u + (unsigned)row) * (unsigned)sizeof(T);
+                    *reinterpret_cast<T*>(gE_ + (size_t)eo_) = e;
+                } else {
+                    reinterpret_cast<T*>(a.e)[(int64_t)inst * 24 + row] = e;
+                }
+            }
         }
         T Gt[3] = {T(0), T(0), T(0)}, Gc[3] = {T(0), T(0), T(0)};
         if constexpr (DPPR) {
@@ -3202,6 +3216,43 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
 #if defined(ESKF_X_PRIO) && ESKF_X_PRIO >= 2
     __builtin_amdgcn_s_setprio(2);          // ... and let a finished one leave
 #endif
+    if constexpr (LPI == 32 && ESKF_PACKED_IMAGE) {
+        // 32 lanes per instance: the rows go into LDS in the ORDER OF THE PACKED RECORD (row h starts at word 25 h or
+        // 26 (23 - h) + 1 and holds its elements 0..h), so the record leaves as a straight copy -- one 16-byte LDS read
+        // and one 16-byte store per piece, no table of image positions (three loads), no per-word reads.  Element j
+        // exists in rows >= j only: a constant set of lanes per j.
+        const int st_ = row < 12 ? 25 * row : 26 * (23 - row) + 1;
+        T* rp_ = sB + st_;
+        static_for<0, 24>([&](auto JJ) {
+            constexpr int j = decltype(JJ)::value;
+            constexpr unsigned long long m32 = (0x00ffffffull >> j) << j, m64 = m32 | (m32 << 32);
+            if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[j]);
+        });
+        gsync();
+        if (valid) {
+            // (wave-uniform base + unsigned 32-bit lane offset, the piece's constant in the offset field -- as for the loads)
+            const int i0_ = vblock * G;
+            char* gPb_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.P) + (int64_t)i0_ * 300);
+            const unsigned so_ = (unsigned)(inst - i0_) * (unsigned)(300 * sizeof(T)) + 16u * (unsigned)lig;
+            TP v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int e_ = lig + k * LPI;
+                // (volatile: all the reads stay in front of the stores, the clamped last one included -- read inside its
+                //  store's predicate it is one more LDS round trip at the very end of the wavefront's life)
+                typedef T piece_vec_t __attribute__((ext_vector_type(PW)));
+                typedef const volatile __attribute__((address_space(3))) piece_vec_t lds_piece_t;
+                const piece_vec_t t_ = *(lds_piece_t*)(sB + PW * (e_ < NPC ? e_ : NPC - 1));
+                static_assert(sizeof(piece_vec_t) == sizeof(TP), "16-byte pieces");
+                __builtin_memcpy(&v[k], &t_, sizeof(TP));
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int e_ = lig + k * LPI;
+                if (e_ < NPC) *reinterpret_cast<TP*>(gPb_ + (size_t)so_ + (size_t)(16 * LPI * k)) = v[k];
+            }
+        }
+    } else {
     if (active) {   // (the whole row: the words above the diagonal are never read)
 #pragma unroll
         for (int j = 0; j < 24; ++j) lds_store1(sB + row * PS + j, p[j]);
@@ -3224,6 +3275,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             const int e_ = lig + k * LPI;
             if (e_ < NPC) gPp[e_] = v[k];
         }
+    }
     }
     ESKF_CSTAMP(5)
 #ifdef ESKF_X_STAMPS
