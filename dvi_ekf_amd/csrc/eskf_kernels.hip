@@ -2699,6 +2699,9 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
+#ifndef ESKF_ROWS_VIA_LDS
+#define ESKF_ROWS_VIA_LDS 1
+#endif
 #ifndef ESKF_PACKED_IMAGE
 #define ESKF_PACKED_IMAGE 1
 #endif
@@ -2897,8 +2900,8 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
     T p[24];                                // row `row` of P
     ESKF_CSTAMP(0)
-    if constexpr (DPPJ && sizeof(T) == 8) {
-        // everything this wavefront reads is requested in one go -- the 24 row elements first, then the
+    if constexpr (DPPJ && (sizeof(T) == 8 || ESKF_ROWS_VIA_LDS)) {
+        // everything this wavefront reads is requested in one go -- the packed covariance first, then the
         // Jacobian record and the residual -- and waited for once: one memory round trip, not two
         T j0[NJ];
         T2 r0;
@@ -2906,8 +2909,52 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
 #ifdef ESKF_X_PRIO
         __builtin_amdgcn_s_setprio(3);      // a new wavefront is the youngest on its SIMD: let it get its requests out
 #endif
+#if ESKF_ROWS_VIA_LDS
+        // The packed record arrives as coalesced 16-byte pieces (five per lane in fp64, three in fp32), goes into LDS in
+        // its own order and is gathered from there: P[row][j] = packed[max(row, j)][min(row, j)], the lane set of either
+        // case a constant of the layout (select_lanes_ge), the element's constant in the read's offset field.  Round 2
+        // had replaced exactly this by 24 direct eight-byte loads per lane when the kernel was bound by its LDS traffic;
+        // with the Jacobian entries and the update's columns on DPP operands it is the memory instructions that
+        // count (24 + 3 loads -> 5 + 3: +4 % on the step, same box).
+        typedef T row_piece_t __attribute__((ext_vector_type(PW)));
+        row_piece_t pv_[NV];
+        {
+            const int i0_ = vblock * G;
+            const char* gPb_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300);
+            const unsigned so_ = (unsigned)(inst - i0_) * (unsigned)(300 * sizeof(T));
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int e_ = lig + k * LPI;
+                pv_[k] = *reinterpret_cast<const row_piece_t*>(gPb_ + (size_t)(so_ + 16u * (unsigned)(e_ < NPC ? e_ : NPC - 1)));
+            }
+        }
+        ESKF_LOAD_J(j0, r0, inst, 0)
+        {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int e_ = lig + k * LPI;
+                *reinterpret_cast<row_piece_t*>(sB + PW * (e_ < NPC ? e_ : NPC - 1)) = pv_[k];
+            }
+            gsync();
+            const unsigned rw_ = (unsigned)row;
+            // (LDS byte addresses: the region's base is part of both alternatives, so nothing is added after the select)
+            const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sB;
+            constexpr unsigned ES = (unsigned)sizeof(T);
+            const unsigned va_ = lb_ + ES * (rw_ < 12u ? 25u * rw_ : 26u * (23u - rw_) + 1u), vb_ = lb_ + ES * rw_;
+            static_for<0, 24>([&](auto JJ) {
+                constexpr int j = decltype(JJ)::value;
+                constexpr unsigned cj_ = ES * (unsigned)(j < 12 ? 25 * j : 26 * (23 - j) + 1), e8_ = ES * (unsigned)j;
+                constexpr unsigned mj_ = cj_ < e8_ ? cj_ : e8_;
+                const unsigned o_ = rowk::select_lanes_ge<true>(j, va_ + (e8_ - mj_), vb_ + (cj_ - mj_), rw_);
+                typedef const volatile __attribute__((address_space(3))) T lds_elem_t;
+                p[j] = *(lds_elem_t*)(size_t)(o_ + mj_);
+            });
+            gsync();
+        }
+#else
         ESKF_ISSUE_ROW()
         ESKF_LOAD_J(j0, r0, inst, 0)
+#endif
 #ifdef ESKF_X_PRIO
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_setprio(0);
