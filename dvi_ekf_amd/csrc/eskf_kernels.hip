@@ -2430,6 +2430,127 @@ __device__ __forceinline__ unsigned long long unusable_pivot_mask(float v) {
     return m;
 }
 
+// The gather of a row from the packed-order LDS image (32 lanes per instance) without address arithmetic: for element j
+// the lanes whose own row holds it (row >= j, bits j..31 of each half: rows, and the idle lanes that shadow row 23) read
+// at row start + j, the others at start of row j + row -- two reads under constant execution masks, the element's
+// constants in the offset fields, instead of one read behind an add and a select (-46 vector instructions per
+// wavefront; the kernel pays for vector instructions, not for LDS reads or scalar moves: +1.4 %, six alternations).
+// va = LDS byte address of the lane's packed row, vb = LDS byte address of word `row` of the image.  The reads are
+// invisible to the compiler's counter logic: the block waits for them itself.  (Text generated: row h of the packed
+// record starts at word 25 h for h < 12, else 26 (23 - h) + 1.)
+__device__ __forceinline__ void gather_row_masked(unsigned va, unsigned vb, double (&p)[24]) {
+    asm volatile(
+        "ds_read_b64 %0, %24\n"
+        "s_mov_b32 exec_lo, 0xfffffffe\n s_mov_b32 exec_hi, 0xfffffffe\n ds_read_b64 %1, %24 offset:8\n"
+        "s_mov_b32 exec_lo, 0x00000001\n s_mov_b32 exec_hi, 0x00000001\n ds_read_b64 %1, %25 offset:200\n"
+        "s_mov_b32 exec_lo, 0xfffffffc\n s_mov_b32 exec_hi, 0xfffffffc\n ds_read_b64 %2, %24 offset:16\n"
+        "s_mov_b32 exec_lo, 0x00000003\n s_mov_b32 exec_hi, 0x00000003\n ds_read_b64 %2, %25 offset:400\n"
+        "s_mov_b32 exec_lo, 0xfffffff8\n s_mov_b32 exec_hi, 0xfffffff8\n ds_read_b64 %3, %24 offset:24\n"
+        "s_mov_b32 exec_lo, 0x00000007\n s_mov_b32 exec_hi, 0x00000007\n ds_read_b64 %3, %25 offset:600\n"
+        "s_mov_b32 exec_lo, 0xfffffff0\n s_mov_b32 exec_hi, 0xfffffff0\n ds_read_b64 %4, %24 offset:32\n"
+        "s_mov_b32 exec_lo, 0x0000000f\n s_mov_b32 exec_hi, 0x0000000f\n ds_read_b64 %4, %25 offset:800\n"
+        "s_mov_b32 exec_lo, 0xffffffe0\n s_mov_b32 exec_hi, 0xffffffe0\n ds_read_b64 %5, %24 offset:40\n"
+        "s_mov_b32 exec_lo, 0x0000001f\n s_mov_b32 exec_hi, 0x0000001f\n ds_read_b64 %5, %25 offset:1000\n"
+        "s_mov_b32 exec_lo, 0xffffffc0\n s_mov_b32 exec_hi, 0xffffffc0\n ds_read_b64 %6, %24 offset:48\n"
+        "s_mov_b32 exec_lo, 0x0000003f\n s_mov_b32 exec_hi, 0x0000003f\n ds_read_b64 %6, %25 offset:1200\n"
+        "s_mov_b32 exec_lo, 0xffffff80\n s_mov_b32 exec_hi, 0xffffff80\n ds_read_b64 %7, %24 offset:56\n"
+        "s_mov_b32 exec_lo, 0x0000007f\n s_mov_b32 exec_hi, 0x0000007f\n ds_read_b64 %7, %25 offset:1400\n"
+        "s_mov_b32 exec_lo, 0xffffff00\n s_mov_b32 exec_hi, 0xffffff00\n ds_read_b64 %8, %24 offset:64\n"
+        "s_mov_b32 exec_lo, 0x000000ff\n s_mov_b32 exec_hi, 0x000000ff\n ds_read_b64 %8, %25 offset:1600\n"
+        "s_mov_b32 exec_lo, 0xfffffe00\n s_mov_b32 exec_hi, 0xfffffe00\n ds_read_b64 %9, %24 offset:72\n"
+        "s_mov_b32 exec_lo, 0x000001ff\n s_mov_b32 exec_hi, 0x000001ff\n ds_read_b64 %9, %25 offset:1800\n"
+        "s_mov_b32 exec_lo, 0xfffffc00\n s_mov_b32 exec_hi, 0xfffffc00\n ds_read_b64 %10, %24 offset:80\n"
+        "s_mov_b32 exec_lo, 0x000003ff\n s_mov_b32 exec_hi, 0x000003ff\n ds_read_b64 %10, %25 offset:2000\n"
+        "s_mov_b32 exec_lo, 0xfffff800\n s_mov_b32 exec_hi, 0xfffff800\n ds_read_b64 %11, %24 offset:88\n"
+        "s_mov_b32 exec_lo, 0x000007ff\n s_mov_b32 exec_hi, 0x000007ff\n ds_read_b64 %11, %25 offset:2200\n"
+        "s_mov_b32 exec_lo, 0xfffff000\n s_mov_b32 exec_hi, 0xfffff000\n ds_read_b64 %12, %24 offset:96\n"
+        "s_mov_b32 exec_lo, 0x00000fff\n s_mov_b32 exec_hi, 0x00000fff\n ds_read_b64 %12, %25 offset:2296\n"
+        "s_mov_b32 exec_lo, 0xffffe000\n s_mov_b32 exec_hi, 0xffffe000\n ds_read_b64 %13, %24 offset:104\n"
+        "s_mov_b32 exec_lo, 0x00001fff\n s_mov_b32 exec_hi, 0x00001fff\n ds_read_b64 %13, %25 offset:2088\n"
+        "s_mov_b32 exec_lo, 0xffffc000\n s_mov_b32 exec_hi, 0xffffc000\n ds_read_b64 %14, %24 offset:112\n"
+        "s_mov_b32 exec_lo, 0x00003fff\n s_mov_b32 exec_hi, 0x00003fff\n ds_read_b64 %14, %25 offset:1880\n"
+        "s_mov_b32 exec_lo, 0xffff8000\n s_mov_b32 exec_hi, 0xffff8000\n ds_read_b64 %15, %24 offset:120\n"
+        "s_mov_b32 exec_lo, 0x00007fff\n s_mov_b32 exec_hi, 0x00007fff\n ds_read_b64 %15, %25 offset:1672\n"
+        "s_mov_b32 exec_lo, 0xffff0000\n s_mov_b32 exec_hi, 0xffff0000\n ds_read_b64 %16, %24 offset:128\n"
+        "s_mov_b32 exec_lo, 0x0000ffff\n s_mov_b32 exec_hi, 0x0000ffff\n ds_read_b64 %16, %25 offset:1464\n"
+        "s_mov_b32 exec_lo, 0xfffe0000\n s_mov_b32 exec_hi, 0xfffe0000\n ds_read_b64 %17, %24 offset:136\n"
+        "s_mov_b32 exec_lo, 0x0001ffff\n s_mov_b32 exec_hi, 0x0001ffff\n ds_read_b64 %17, %25 offset:1256\n"
+        "s_mov_b32 exec_lo, 0xfffc0000\n s_mov_b32 exec_hi, 0xfffc0000\n ds_read_b64 %18, %24 offset:144\n"
+        "s_mov_b32 exec_lo, 0x0003ffff\n s_mov_b32 exec_hi, 0x0003ffff\n ds_read_b64 %18, %25 offset:1048\n"
+        "s_mov_b32 exec_lo, 0xfff80000\n s_mov_b32 exec_hi, 0xfff80000\n ds_read_b64 %19, %24 offset:152\n"
+        "s_mov_b32 exec_lo, 0x0007ffff\n s_mov_b32 exec_hi, 0x0007ffff\n ds_read_b64 %19, %25 offset:840\n"
+        "s_mov_b32 exec_lo, 0xfff00000\n s_mov_b32 exec_hi, 0xfff00000\n ds_read_b64 %20, %24 offset:160\n"
+        "s_mov_b32 exec_lo, 0x000fffff\n s_mov_b32 exec_hi, 0x000fffff\n ds_read_b64 %20, %25 offset:632\n"
+        "s_mov_b32 exec_lo, 0xffe00000\n s_mov_b32 exec_hi, 0xffe00000\n ds_read_b64 %21, %24 offset:168\n"
+        "s_mov_b32 exec_lo, 0x001fffff\n s_mov_b32 exec_hi, 0x001fffff\n ds_read_b64 %21, %25 offset:424\n"
+        "s_mov_b32 exec_lo, 0xffc00000\n s_mov_b32 exec_hi, 0xffc00000\n ds_read_b64 %22, %24 offset:176\n"
+        "s_mov_b32 exec_lo, 0x003fffff\n s_mov_b32 exec_hi, 0x003fffff\n ds_read_b64 %22, %25 offset:216\n"
+        "s_mov_b32 exec_lo, 0xff800000\n s_mov_b32 exec_hi, 0xff800000\n ds_read_b64 %23, %24 offset:184\n"
+        "s_mov_b32 exec_lo, 0x007fffff\n s_mov_b32 exec_hi, 0x007fffff\n ds_read_b64 %23, %25 offset:8\n"
+        "s_mov_b64 exec, -1\n s_waitcnt lgkmcnt(0)\n"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]),
+          "=&v"(p[8]), "=&v"(p[9]), "=&v"(p[10]), "=&v"(p[11]), "=&v"(p[12]), "=&v"(p[13]), "=&v"(p[14]), "=&v"(p[15]),
+          "=&v"(p[16]), "=&v"(p[17]), "=&v"(p[18]), "=&v"(p[19]), "=&v"(p[20]), "=&v"(p[21]), "=&v"(p[22]), "=&v"(p[23])
+        : "v"(va), "v"(vb)
+        : "memory");
+}
+__device__ __forceinline__ void gather_row_masked(unsigned va, unsigned vb, float (&p)[24]) {
+    asm volatile(
+        "ds_read_b32 %0, %24\n"
+        "s_mov_b32 exec_lo, 0xfffffffe\n s_mov_b32 exec_hi, 0xfffffffe\n ds_read_b32 %1, %24 offset:4\n"
+        "s_mov_b32 exec_lo, 0x00000001\n s_mov_b32 exec_hi, 0x00000001\n ds_read_b32 %1, %25 offset:100\n"
+        "s_mov_b32 exec_lo, 0xfffffffc\n s_mov_b32 exec_hi, 0xfffffffc\n ds_read_b32 %2, %24 offset:8\n"
+        "s_mov_b32 exec_lo, 0x00000003\n s_mov_b32 exec_hi, 0x00000003\n ds_read_b32 %2, %25 offset:200\n"
+        "s_mov_b32 exec_lo, 0xfffffff8\n s_mov_b32 exec_hi, 0xfffffff8\n ds_read_b32 %3, %24 offset:12\n"
+        "s_mov_b32 exec_lo, 0x00000007\n s_mov_b32 exec_hi, 0x00000007\n ds_read_b32 %3, %25 offset:300\n"
+        "s_mov_b32 exec_lo, 0xfffffff0\n s_mov_b32 exec_hi, 0xfffffff0\n ds_read_b32 %4, %24 offset:16\n"
+        "s_mov_b32 exec_lo, 0x0000000f\n s_mov_b32 exec_hi, 0x0000000f\n ds_read_b32 %4, %25 offset:400\n"
+        "s_mov_b32 exec_lo, 0xffffffe0\n s_mov_b32 exec_hi, 0xffffffe0\n ds_read_b32 %5, %24 offset:20\n"
+        "s_mov_b32 exec_lo, 0x0000001f\n s_mov_b32 exec_hi, 0x0000001f\n ds_read_b32 %5, %25 offset:500\n"
+        "s_mov_b32 exec_lo, 0xffffffc0\n s_mov_b32 exec_hi, 0xffffffc0\n ds_read_b32 %6, %24 offset:24\n"
+        "s_mov_b32 exec_lo, 0x0000003f\n s_mov_b32 exec_hi, 0x0000003f\n ds_read_b32 %6, %25 offset:600\n"
+        "s_mov_b32 exec_lo, 0xffffff80\n s_mov_b32 exec_hi, 0xffffff80\n ds_read_b32 %7, %24 offset:28\n"
+        "s_mov_b32 exec_lo, 0x0000007f\n s_mov_b32 exec_hi, 0x0000007f\n ds_read_b32 %7, %25 offset:700\n"
+        "s_mov_b32 exec_lo, 0xffffff00\n s_mov_b32 exec_hi, 0xffffff00\n ds_read_b32 %8, %24 offset:32\n"
+        "s_mov_b32 exec_lo, 0x000000ff\n s_mov_b32 exec_hi, 0x000000ff\n ds_read_b32 %8, %25 offset:800\n"
+        "s_mov_b32 exec_lo, 0xfffffe00\n s_mov_b32 exec_hi, 0xfffffe00\n ds_read_b32 %9, %24 offset:36\n"
+        "s_mov_b32 exec_lo, 0x000001ff\n s_mov_b32 exec_hi, 0x000001ff\n ds_read_b32 %9, %25 offset:900\n"
+        "s_mov_b32 exec_lo, 0xfffffc00\n s_mov_b32 exec_hi, 0xfffffc00\n ds_read_b32 %10, %24 offset:40\n"
+        "s_mov_b32 exec_lo, 0x000003ff\n s_mov_b32 exec_hi, 0x000003ff\n ds_read_b32 %10, %25 offset:1000\n"
+        "s_mov_b32 exec_lo, 0xfffff800\n s_mov_b32 exec_hi, 0xfffff800\n ds_read_b32 %11, %24 offset:44\n"
+        "s_mov_b32 exec_lo, 0x000007ff\n s_mov_b32 exec_hi, 0x000007ff\n ds_read_b32 %11, %25 offset:1100\n"
+        "s_mov_b32 exec_lo, 0xfffff000\n s_mov_b32 exec_hi, 0xfffff000\n ds_read_b32 %12, %24 offset:48\n"
+        "s_mov_b32 exec_lo, 0x00000fff\n s_mov_b32 exec_hi, 0x00000fff\n ds_read_b32 %12, %25 offset:1148\n"
+        "s_mov_b32 exec_lo, 0xffffe000\n s_mov_b32 exec_hi, 0xffffe000\n ds_read_b32 %13, %24 offset:52\n"
+        "s_mov_b32 exec_lo, 0x00001fff\n s_mov_b32 exec_hi, 0x00001fff\n ds_read_b32 %13, %25 offset:1044\n"
+        "s_mov_b32 exec_lo, 0xffffc000\n s_mov_b32 exec_hi, 0xffffc000\n ds_read_b32 %14, %24 offset:56\n"
+        "s_mov_b32 exec_lo, 0x00003fff\n s_mov_b32 exec_hi, 0x00003fff\n ds_read_b32 %14, %25 offset:940\n"
+        "s_mov_b32 exec_lo, 0xffff8000\n s_mov_b32 exec_hi, 0xffff8000\n ds_read_b32 %15, %24 offset:60\n"
+        "s_mov_b32 exec_lo, 0x00007fff\n s_mov_b32 exec_hi, 0x00007fff\n ds_read_b32 %15, %25 offset:836\n"
+        "s_mov_b32 exec_lo, 0xffff0000\n s_mov_b32 exec_hi, 0xffff0000\n ds_read_b32 %16, %24 offset:64\n"
+        "s_mov_b32 exec_lo, 0x0000ffff\n s_mov_b32 exec_hi, 0x0000ffff\n ds_read_b32 %16, %25 offset:732\n"
+        "s_mov_b32 exec_lo, 0xfffe0000\n s_mov_b32 exec_hi, 0xfffe0000\n ds_read_b32 %17, %24 offset:68\n"
+        "s_mov_b32 exec_lo, 0x0001ffff\n s_mov_b32 exec_hi, 0x0001ffff\n ds_read_b32 %17, %25 offset:628\n"
+        "s_mov_b32 exec_lo, 0xfffc0000\n s_mov_b32 exec_hi, 0xfffc0000\n ds_read_b32 %18, %24 offset:72\n"
+        "s_mov_b32 exec_lo, 0x0003ffff\n s_mov_b32 exec_hi, 0x0003ffff\n ds_read_b32 %18, %25 offset:524\n"
+        "s_mov_b32 exec_lo, 0xfff80000\n s_mov_b32 exec_hi, 0xfff80000\n ds_read_b32 %19, %24 offset:76\n"
+        "s_mov_b32 exec_lo, 0x0007ffff\n s_mov_b32 exec_hi, 0x0007ffff\n ds_read_b32 %19, %25 offset:420\n"
+        "s_mov_b32 exec_lo, 0xfff00000\n s_mov_b32 exec_hi, 0xfff00000\n ds_read_b32 %20, %24 offset:80\n"
+        "s_mov_b32 exec_lo, 0x000fffff\n s_mov_b32 exec_hi, 0x000fffff\n ds_read_b32 %20, %25 offset:316\n"
+        "s_mov_b32 exec_lo, 0xffe00000\n s_mov_b32 exec_hi, 0xffe00000\n ds_read_b32 %21, %24 offset:84\n"
+        "s_mov_b32 exec_lo, 0x001fffff\n s_mov_b32 exec_hi, 0x001fffff\n ds_read_b32 %21, %25 offset:212\n"
+        "s_mov_b32 exec_lo, 0xffc00000\n s_mov_b32 exec_hi, 0xffc00000\n ds_read_b32 %22, %24 offset:88\n"
+        "s_mov_b32 exec_lo, 0x003fffff\n s_mov_b32 exec_hi, 0x003fffff\n ds_read_b32 %22, %25 offset:108\n"
+        "s_mov_b32 exec_lo, 0xff800000\n s_mov_b32 exec_hi, 0xff800000\n ds_read_b32 %23, %24 offset:92\n"
+        "s_mov_b32 exec_lo, 0x007fffff\n s_mov_b32 exec_hi, 0x007fffff\n ds_read_b32 %23, %25 offset:4\n"
+        "s_mov_b64 exec, -1\n s_waitcnt lgkmcnt(0)\n"
+        : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]),
+          "=&v"(p[8]), "=&v"(p[9]), "=&v"(p[10]), "=&v"(p[11]), "=&v"(p[12]), "=&v"(p[13]), "=&v"(p[14]), "=&v"(p[15]),
+          "=&v"(p[16]), "=&v"(p[17]), "=&v"(p[18]), "=&v"(p[19]), "=&v"(p[20]), "=&v"(p[21]), "=&v"(p[22]), "=&v"(p[23])
+        : "v"(va), "v"(vb)
+        : "memory");
+}
+
 // ---- cross-lane broadcast without LDS (32 lanes per instance; fp64 shown, fp32 below) --------------
 // An instance occupies two 16-lane DPP rows: rows 0..15 of P in the first, rows 16..23 (+ 8 shadow
 // lanes) in the second.  `row_newbcast:n` feeds lane n of the reader's own 16-lane row to every lane
@@ -2699,6 +2820,9 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // with the Jacobian record in registers (JRegs) and the update's columns handed around as DPP operands the
 // kernel needs 640 LDS words per instance (exchange image 600, error state 24, residual 8) and <= 128
 // VGPRs: four wavefronts per SIMD, sixteen per CU.
+#ifndef ESKF_GATHER_MASKED
+#define ESKF_GATHER_MASKED 1
+#endif
 #ifndef ESKF_ROWS_VIA_LDS
 #define ESKF_ROWS_VIA_LDS 1
 #endif
@@ -2941,6 +3065,8 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
             const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sB;
             constexpr unsigned ES = (unsigned)sizeof(T);
             const unsigned va_ = lb_ + ES * (rw_ < 12u ? 25u * rw_ : 26u * (23u - rw_) + 1u), vb_ = lb_ + ES * rw_;
+            if constexpr (ESKF_GATHER_MASKED) rowk::gather_row_masked(va_, vb_, p);
+            else
             static_for<0, 24>([&](auto JJ) {
                 constexpr int j = decltype(JJ)::value;
                 constexpr unsigned cj_ = ES * (unsigned)(j < 12 ? 25 * j : 26 * (23 - j) + 1), e8_ = ES * (unsigned)j;
