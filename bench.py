@@ -431,11 +431,16 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch") if B == 65536 else None     # (measured at the headline batch)
-                traffic_source = ("static: profiles/traffic_per_launch.json -- a constant taken from the committed rocprofv3 "
-                                  "PMC pass of this kernel pair (FETCH_SIZE x2 + WRITE_SIZE per step), NOT measured in this run")
+                # (the PMC pass measured exactly one configuration: the default fp64 pair step at the headline batch through
+                #  the library's default kernels, shared noise model, restore by reading the snapshot -- nothing else gets it)
+                measured_cfg = (B == 65536 and args.lanes == 0 and args.mode == "pair" and not args.per_instance_noise
+                                and not args.restore_copy and not os.environ.get("DVI_ESKF_LIB"))
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch") if measured_cfg else None
             except Exception:
                 traffic = None
+            if traffic is not None:
+                traffic_source = ("static: profiles/traffic_per_launch.json -- a constant taken from the committed rocprofv3 "
+                                  "PMC pass of this kernel pair (FETCH_SIZE x2 + WRITE_SIZE per step), NOT measured in this run")
         # A yardstick next to the 8 TB/s figure: the rate at which this box copies a buffer of the step's own measured
         # traffic (half read, half written) -- what its memory system gives the simplest kernel with the same mix.
         yardstick = None
@@ -488,7 +493,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "valid": ok and args.mode == "pair",
+            # (a line measured with an experiment build of the library -- DVI_ESKF_LIB -- is never a valid bench line)
+            "valid": ok and args.mode == "pair" and not os.environ.get("DVI_ESKF_LIB"),
+            "all_instances_ok": ok,
             "config": {
                 "workload": "BASELINE config #2/#4: Monte-Carlo batch on mandala0_mono, 1:1 predict+update "
                             "pairs (dt=1.0), unfrozen DOFs, per-instance IMU/camera noise and perturbed ICs",
@@ -502,6 +509,7 @@ def main():
                                 if graph else "steps launched from Python",
                 "untimed_preparation": "%d warm-up steps, graph capture and one launch of every captured graph, then %d replayed steps (%.2f s) to reach sustained clocks"
                                        % (W, sustained_steps, args.sustain_seconds),
+                **({"library_override": os.environ["DVI_ESKF_LIB"]} if os.environ.get("DVI_ESKF_LIB") else {}),
                 "final_collective": ("RCCL all_gather of dofs[B,6]" if backend == "nccl" else "gloo all_gather of dofs[B,6] (rehearsal)")
                                     if dist is not None else "none (single GPU)",
             },

@@ -11,6 +11,14 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvi_eskf.so")
+# Experiment builds (tools/ab_lib.sh, tools/prof_variant.sh) are selected per process with DVI_ESKF_LIB=<path> instead
+# of being copied over the committed library: an interrupted A/B run then leaves nothing behind.  lib_path() is what
+# bench.py reports, so that a line measured with another build says so.
+LIB_OVERRIDE_ENV = "DVI_ESKF_LIB"
+
+
+def lib_path() -> str:
+    return os.environ.get(LIB_OVERRIDE_ENV) or LIB_PATH
 
 F64, F32 = 0, 1
 STATUS_SINGULAR, STATUS_NONFINITE = 1, 2
@@ -80,14 +88,15 @@ _lib = None
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = lib_path()
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} not found: the HIP library is required (build it with "
+                f"{path} not found: the HIP library is required (build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C dvi_ekf_amd/csrc`)")
         # PyTorch must be loaded first: the library has to bind to the HIP runtime that
         # PyTorch ships, otherwise torch's streams / device pointers belong to another runtime
         import torch  # noqa: F401
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the symbol is missing
             fn.restype = res

@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box): tools/prof_variant.sh <tag> [variants_tmp/lib_X.so]  -- kernel stats of bench.py with a prebuilt library variant
 tag=$1; lib=$2
-cp dvi_ekf_amd/libdvi_eskf.so /tmp/lib_orig.so
-[ -n "$lib" ] && cp $lib dvi_ekf_amd/libdvi_eskf.so
+# (the variant is selected per process -- DVI_ESKF_LIB, dvi_ekf_amd/_capi.py -- the committed library is never replaced)
+[ -n "$lib" ] && export DVI_ESKF_LIB=$PWD/$lib
 R=$PWD
 mkdir -p gpurun_out/$tag
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/prof -- python3 $R/bench.py --steps 256 --warmup 16 --no-cpu-baseline --no-streaming > $R/gpurun_out/$tag/bench.json 2> $R/gpurun_out/$tag/bench.err)
@@ -14,4 +14,3 @@ for r in list(csv.DictReader(open(f)))[:4]:
 d = json.load(open("gpurun_out/$tag/bench.json")); print("$tag", "value %.3e frac %.4f kernel_ms %.4f valid %s" % (d["value"], d["roofline"]["frac"], d["roofline"]["kernel_ms"], d["valid"]))
 PY
 rm -f gpurun_out/$tag/prof/*/*kernel_trace.csv
-cp /tmp/lib_orig.so dvi_ekf_amd/libdvi_eskf.so
