@@ -28,6 +28,8 @@
 #include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stddef.h>
+#include <stdio.h>
 
 #include "eskf_device.h"
 
@@ -939,16 +941,19 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
     for (int i = 0; i < n; ++i) dst[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i0 + i];
 #endif
 }
-template <typename T>
+// KEEP (eskf_step_kernel): the block's first NI lanes carry its NI instances and the records STAY in the staging rows --
+// the covariance rounds of the same block take them from there; nothing is written to a.J.
+template <typename T, bool KEEP = false, int NI = 64>
 __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock) {
     T* sJ = reinterpret_cast<T*>(smem_raw);
-    const int JS = prm.jfull ? J_FULL : J_CORE;        // staging rows = whole records: residual words, then the blocks (odd: conflict-free)
+    const int JS = (!KEEP && prm.jfull) ? J_FULL : J_CORE;   // staging rows = whole records: residual words, then the blocks (odd: conflict-free)
     const int lane = threadIdx.x & 63;
-    const int role = threadIdx.x >> 6;                 // wave-uniform
-    const int64_t b0 = (int64_t)vblock * 64;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform, and known to be
+    const int64_t b0 = (int64_t)vblock * NI;
     const int64_t b_raw = b0 + lane;
-    const bool live = b_raw < a.B;
-    const int64_t b = live ? b_raw : a.B - 1;          // tail lanes recompute the last instance, write nothing
+    const bool live = (NI == 64 || lane < NI) && b_raw < a.B;
+    const int64_t b_last = (b0 + NI - 1 < a.B) ? b0 + NI - 1 : a.B - 1;
+    const int64_t b = live ? b_raw : b_last;           // tail lanes recompute the block's last instance, write nothing
     const T* xi = reinterpret_cast<const T*>(a.xs_src);
     T* xo = reinterpret_cast<T*>(a.xs);
     const int64_t B = a.B;
@@ -1242,12 +1247,14 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
     if (role == 0) ESKF_STAMP(4)
     if (role != 1) __syncthreads();                     // barrier 2: the 64 staged records are complete
     if (role == 0) ESKF_STAMP(5)
-    {
+    if constexpr (!KEEP) {
         T* gJ = reinterpret_cast<T*>(a.J) + b0 * JW;
         const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
         const int first = role * 16, last = (first + 16 < nrec) ? first + 16 : nrec;
+#ifndef ESKF_X_NO_RECSTORE  // timing experiment only: the records never leave the block
         if (prm.jfull) store_records<T, J_FULL>(sJ, gJ, last, lane, first);
         else store_records<T, J_CORE>(sJ, gJ, last, lane, first);
+#endif
     }
     if (role == 0) ESKF_STAMP(6)
 #ifdef ESKF_X_STAMPS
@@ -2829,21 +2836,67 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 #ifndef ESKF_PACKED_IMAGE
 #define ESKF_PACKED_IMAGE 1
 #endif
+#ifdef ESKF_X_JHOT          // timing experiment only (wrong numbers): every wavefront reads the records of instances 0 / 1 --
+#define ESKF_X_JHOT_SEL(A, B) (A)   // what the covariance kernel costs when its Jacobian records cost no traffic
+#else
+#define ESKF_X_JHOT_SEL(A, B) (B)
+#endif
 #ifdef ESKF_X_NT_JLOADS     // experiment: records are read exactly once
 #define ESKF_LDJ(p) __builtin_nontemporal_load(p)
 #else
 #define ESKF_LDJ(p) (*(p))
 #endif
-template <typename T, bool PIN, int LPI, bool SLIM>
-__device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams<T>& prm, T* smem, const int vblock, const int lane) {
-    auto gsync = [&]() { group_sync(); };
+// WAVE (eskf_step_kernel): the wavefront is one of several of its block, each working through pairs of instances on its
+// own: the exchanges through LDS are wave-local (LDS instructions of one wavefront execute in order -- only the
+// compiler has to be kept from moving them across), the region is the 600-word image alone, and the first predict's
+// record comes from the registers `jpre` (words lig, 32 + lig, 64 + lig of the record the block's pre phase left in LDS)
+// instead of from a.J.
+// The kernel's own arguments as they lie in the kernarg segment (constant address space).  A wavefront of
+// eskf_step_kernel that works through several pairs re-reads what it needs from there at three points of every round
+// (cov_rows_body<WAVE>::refresh_args) through a pointer the compiler cannot see through: 106 dwords of arguments are more
+// than a wavefront has scalar registers, and read once in front of the round loop they are all kept live across it --
+// what does not fit is parked in lanes of vector registers, 260 v_readlane / v_writelane per round (a third on top of
+// the round's own vector instructions; measured on the first build of that kernel).
+template <typename T>
+struct StepKernArgs { StepArgs a; DevParams<T> prm; };
+template <typename S>
+__device__ __forceinline__ S load_kernarg(const char __attribute__((address_space(4))) * p) {
+    static_assert(sizeof(S) % 4 == 0, "whole dwords");
+    S r;
+    const uint32_t __attribute__((address_space(4))) * w = (const uint32_t __attribute__((address_space(4))) *)p;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(S) / 4; ++i) reinterpret_cast<uint32_t*>(&r)[i] = w[i];
+    return r;
+}
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <typename T, bool PIN, int LPI, bool SLIM, bool WAVE = false>
+__device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevParams<T>& prm_in, T* smem, const int vblock, const int lane,
+                                              const T* jpre = nullptr) {
+    StepArgs a = a_in;
+    DevParams<T> prm = prm_in;
+    // WAVE: the arguments as of now, straight from the kernarg segment (see StepKernArgs); whatever was read before is dead
+    auto refresh_args = [&]() {
+        if constexpr (WAVE) {
+            const char __attribute__((address_space(4))) * ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            a = load_kernarg<StepArgs>(ka + offsetof(StepKernArgs<T>, a));
+            prm = load_kernarg<DevParams<T>>(ka + offsetof(StepKernArgs<T>, prm));
+        }
+    };
+    refresh_args();
+    auto gsync = [&]() { if constexpr (WAVE) wave_sync(); else group_sync(); };
     using namespace rowk;
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
     static_assert(!SLIM || LPI == 32, "SLIM: 32 lanes per instance");
+    static_assert(!WAVE || (SLIM && !PIN), "WAVE: the slim build with the shared noise model");
     constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
     constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
     // (with per-instance noise the 24-word noise record follows the residual: 664 words, 15 wavefronts per CU)
-    constexpr int REGION = SLIM ? (PIN ? 664 : 640) : PIN ? R_REGION_PIN : R_REGION;
+    constexpr int REGION = WAVE ? 600 : SLIM ? (PIN ? 664 : 640) : PIN ? R_REGION_PIN : R_REGION;
     constexpr int R_C = SLIM ? 600 : rowk::R_C;
     constexpr int R_RES = SLIM ? 624 : rowk::R_RES;
     constexpr int R_J = SLIM ? 0 : rowk::R_J;      // (SLIM: never addressed)
@@ -2886,9 +2939,9 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         if constexpr (LPI == 32) {                                                                 \
             /* wave-uniform base + unsigned 32-bit lane offset, as for the rows; only the third word of a lane can lie \
                in the padding of the record (words >= 64 + lane), which is not fetched */                      \
-            const int i0_ = vblock * G;                                                            \
+            const int i0_ = ESKF_X_JHOT_SEL(0, vblock * G);                                        \
             const char* gJw_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + i0_) * JW); \
-            const unsigned jo_ = (unsigned)((INST) - i0_) * (unsigned)(JW * sizeof(T));            \
+            const unsigned jo_ = (unsigned)ESKF_X_JHOT_SEL(grp, (INST) - i0_) * (unsigned)(JW * sizeof(T)); \
             const unsigned lo_ = jo_ + (unsigned)lj_ * (unsigned)sizeof(T);                        \
             static_assert(NJ == 3 && J_CORE - 1 >= 64, "three words per lane, the first two never padding"); \
             DST[0] = ESKF_LDJ(reinterpret_cast<const T*>(gJw_ + (size_t)lo_));                      \
@@ -3014,6 +3067,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
         gsync();                                                                              \
         if constexpr (DPPJ) fx_apply_col_dpp(Jr, sB + row, p);                                     \
         else fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */     \
+        refresh_args();                                                                            \
         noise_rows<T, PIN, !SLIM, LPI == 32>(prm, sJ, sN, row, p);                                 \
         gsync();                                                                              \
     }
@@ -3052,7 +3106,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
                 pv_[k] = *reinterpret_cast<const row_piece_t*>(gPb_ + (size_t)(so_ + 16u * (unsigned)(e_ < NPC ? e_ : NPC - 1)));
             }
         }
-        ESKF_LOAD_J(j0, r0, inst, 0)
+        if constexpr (WAVE) {
+#pragma unroll
+            for (int k = 0; k < NJ; ++k) j0[k] = jpre[k];
+        } else {
+            ESKF_LOAD_J(j0, r0, inst, 0)
+        }
         {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
@@ -3169,6 +3228,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a, const DevParams
     pin_row(p);
 #endif
     ESKF_CSTAMP(2)
+    refresh_args();
     T e = T(0);                             // component `row` of the error state
     int status = 0;
     bool fail = false;
@@ -3468,6 +3528,84 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
     constexpr int REGION = SLIM ? (PIN ? 664 : 640) : PIN ? rowk::R_REGION_PIN : rowk::R_REGION;
     __shared__ __attribute__((aligned(16))) T smem[G * REGION];
     cov_rows_body<T, PIN, LPI, SLIM>(a, prm, smem, (int)blockIdx.x + (int)(a.sub_first / G), (int)threadIdx.x);
+}
+
+// ----------------------------------------------------------------------------------
+// eskf_step_kernel: one predict(+update) step in ONE launch, the Jacobian records never leave the chip.
+//
+// A block of eight wavefronts owns NI = 16 ROUNDS instances.  Phase 1: wavefronts 0..3 are the four chains of
+// eskf_pre4_kernel (pre4_body<KEEP>: same code, same bits) on the block's instances, one lane each -- nominal state to
+// HBM, the records (residual + Jacobian blocks, 75 words) into LDS staging rows; wavefronts 4..7 only join the three
+// barriers.  Then every wavefront takes the records of ITS 2 ROUNDS instances out of the staging rows into registers
+// (three words per lane and round), a barrier hands the LDS over, and phase 2 runs ROUNDS rounds of the row-resident
+// covariance step per wavefront (cov_rows_body<WAVE>: the body of eskf_cov_rows_kernel with wave-local exchanges and the
+// first record in registers) on a 600-word image per instance that overlays the staging rows.
+//
+// What it saves over eskf_pre4_kernel + eskf_cov_rows_kernel: the record's round trip through memory (fp64, B = 65 536:
+// 2 x 40 MB of the 477 MB a step moves; builds of the two kernels with the record stores / loads compiled out put the
+// bound at 71.6 us against 87.0) and a kernel boundary.  What it costs: the block's phase 1 is serial with its rounds
+// (two blocks per CU: while one is in phase 1 the other one's eight wavefronts have the CU).
+// ROUNDS = 4: full batches (NI = 64: every lane of phase 1 busy); 2 / 1: batches that would not fill the chip with
+// 64-instance blocks (phase 1 then runs with 32 / 16 of its 64 lanes, which is free on idle SIMDs).
+// Not covered (the launcher falls back to the two kernels): per-instance noise, a gyro block in Q or kept Jacobians
+// (85-word records), gain output, launches over a part of the batch, epochs.
+// ----------------------------------------------------------------------------------
+template <typename T, int ROUNDS>
+__global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
+    constexpr int NI = 16 * ROUNDS;
+    constexpr int WREGION = 2 * 600;                     // words per wavefront: the images of its two instances
+    static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // (the wavefront's number as a SCALAR: everything derived from it -- the role, the image address, the pair index and
+    //  with it the wave-uniform bases of the covariance body's addressing -- stays in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    // ---- phase 1
+    if (wave < 4) {
+        pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x);
+    } else {
+        __syncthreads();                                // barrier 1
+        __syncthreads();                                // barrier 1b
+        __syncthreads();                                // barrier 2: the staged records are complete
+    }
+    // ---- hand-over: the records of this wavefront's instances, three words per lane and round
+    T jr[ROUNDS][3];
+    {
+        const T* sJ = reinterpret_cast<const T*>(smem_raw);
+        const int grp = lane >> 5, lig = lane & 31;
+        const int w2 = lig + 64 < J_CORE - 1 ? lig + 64 : J_CORE - 1;     // (the record ends at word 74)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const T* row = sJ + (wave * 2 * ROUNDS + 2 * r + grp) * J_CORE;
+            jr[r][0] = row[lig];
+            jr[r][1] = row[32 + lig];
+            jr[r][2] = row[w2];
+        }
+    }
+    __syncthreads();                                    // everyone has its records: the rows become exchange images
+    // ---- phase 2
+    T* smem = reinterpret_cast<T*>(smem_raw) + wave * WREGION;
+    const int vb0 = (int)blockIdx.x * (NI / 2) + wave * ROUNDS;
+    const int nB = (int)a.B;
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; ++r) {
+        // a pair that lies entirely beyond the batch (ragged last block) has nothing to do -- and the body's
+        // wave-uniform base + unsigned lane offset addressing needs the pair's first instance to exist
+        if ((vb0 + r) * 2 >= nB) break;
+        // the round's record is always jr[0]: the later ones move up by one afterwards (a handful of register moves per
+        // round; indexed by r -- or selected by compares on r, which the compiler turns back into an index -- the array
+        // would live in scratch, one scratch round trip per round on the counter the round's loads and stores share)
+        T j0[3] = {jr[0][0], jr[0][1], jr[0][2]};
+        // (lane index opaque per round: what the body derives from it -- rows, LDS addresses -- is formed again every
+        //  round instead of being hoisted out of the loop and spilled across it)
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));
+        cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0);
+#pragma unroll
+        for (int q = 0; q + 1 < ROUNDS; ++q)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) jr[q][k] = jr[q + 1][k];
+    }
 }
 
 // state.dofs of every instance (Filter.calculate_dof_metric, Filter.py:452-455; the payload of the final gather)
@@ -3791,9 +3929,65 @@ static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEG
 // largest batch whose epochs go through eskf_nominal_kernel + eskf_jac_kernel (DVI_ESKF_EPOCH_SPLIT_MAX; -1 = always)
 static const int64_t g_epoch_split_max = []() { const char* e = getenv("DVI_ESKF_EPOCH_SPLIT_MAX"); return e ? (int64_t)atoll(e) : (int64_t)40960; }();
 
+// The one-launch step (eskf_step_kernel).  DVI_ESKF_FUSED=0 switches it off, =1 forces it wherever it is able to run
+// (A/B against the two kernels, and the bitwise test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1|2|4 pins
+// the block size.  Default: by batch size, from same-box A/B runs (fp64 pair step of bench.py, pair-steps/s x1e8, two
+// kernels -> one launch with 16 / 32 / 64 instances per block):
+//     B = 1 024  0.89 -> 0.94 / 0.62 / 0.37      4 096  2.69 -> 3.26 / 2.26 / 1.39      8 192  4.05 -> 4.48 / 3.64 / -
+//     16 384  5.65 -> 4.81 / 5.71 / 4.95      32 768  7.03 -> 5.35 / 6.19 / 6.67      65 536  7.25 -> - / 6.44 / 6.90
+//     262 144 (streams from HBM)  6.67-6.81 -> - / - / 6.96
+// fp32 predict-only (config #3), predict-steps/s x1e9: B = 8 192  0.66 -> 0.80; 65 536  1.46 -> 1.38; 262 144  1.43 -> 1.49;
+// 1 048 576  1.23 -> 1.59.
+// A block's pre phase is serial with its covariance rounds, and the blocks of a generation are in it at the same time:
+// that costs more than the record's round trip through memory while a launch is only two generations of blocks (B =
+// 32 768 ... 65 536), and less once a batch under-fills the chip (one generation: latency is what counts) or is many
+// generations long (the blocks drift apart, one block's pre phase runs next to its neighbour's rounds).
+static const int g_fused = []() { const char* e = getenv("DVI_ESKF_FUSED"); return e ? atoi(e) : -1; }();     // -1: by batch
+static const int g_fused_rounds = []() { const char* e = getenv("DVI_ESKF_FUSED_ROUNDS"); return e ? atoi(e) : 0; }();
+static int step_kernel_rounds(int64_t B) {          // 0: the two kernels
+    if (g_fused == 0) return 0;
+    if (g_fused_rounds == 1 || g_fused_rounds == 2 || g_fused_rounds == 4) return g_fused_rounds;
+    if (B <= 12288) return 1;
+    if (B <= 24576) return 2;
+    if (B >= 131072 || g_fused > 0) return 4;
+    return 0;
+}
+// (the kernel asks for 75 KB of LDS per block in fp64: checked once per device against what a block may have)
+static bool device_lds_fits(size_t bytes) {
+    int dev = 0, lim = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
+    return (size_t)lim >= bytes;
+}
+template <typename T>
+static bool step_kernel_covers(int lpi, const StepArgs& a, const DevParams<T>& prm) {
+    static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 600 * sizeof(double));
+    return lds_ok && step_kernel_rounds(a.B) != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count && !prm.jfull &&
+           !prm.q_gyro && a.B < 0x7fffffffLL;
+}
+template <typename T>
+static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
+    const int rounds = step_kernel_rounds(a.B);
+    const size_t lds = (size_t)8 * 2 * 600 * sizeof(T);     // 76 800 B (fp64): two blocks per CU
+    const unsigned blocks = (unsigned)((a.B + 16 * rounds - 1) / (16 * rounds));
+    // (DVI_ESKF_VERBOSE=1: one line on stderr the first time this path is taken -- the tests of the one-launch step
+    //  make sure with it that they are not comparing the two-kernel path with itself)
+    static const bool verbose = []() { const char* e = getenv("DVI_ESKF_VERBOSE"); return e && e[0] == '1'; }();
+    static bool said = false;
+    if (verbose && !said) {
+        said = true;
+        fprintf(stderr, "dvi_eskf: single-predict launches go through eskf_step_kernel (%d instances per block)\n", 16 * rounds);
+    }
+    if (rounds == 4) hipLaunchKernelGGL((eskf_step_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm);
+    else if (rounds == 2) hipLaunchKernelGGL((eskf_step_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm);
+    else hipLaunchKernelGGL((eskf_step_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm);
+    return hipGetLastError();
+}
+
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
+    if (step_kernel_covers(lpi, a, prm)) return launch_step_kernel<T>(a, prm, stream);
     // a part of the batch: only the kernels that honour sub_first / sub_count (the host asks for it under these conditions only)
     if (a.sub_count && (a.n_pred < 2 || g_pre_legacy || !a.aux || a.noise || a.K_out || lpi != 1 || (a.sub_count & 63) || (a.sub_first & 63)))
         return hipErrorInvalidValue;

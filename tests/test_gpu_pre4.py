@@ -24,6 +24,7 @@ def _run(tmp_path, scenario, legacy):
     out = tmp_path / f"{scenario}_{'legacy' if legacy else 'pre4'}.npz"
     env = dict(os.environ)
     env.pop("DVI_ESKF_PRE_LEGACY", None)
+    env["DVI_ESKF_FUSED"] = "0"     # (this file is about the pre kernels: the one-launch step has tests/test_gpu_step_kernel.py)
     if legacy:
         env["DVI_ESKF_PRE_LEGACY"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_pre4_child.py"), scenario, str(out), ROOT], cwd=ROOT,

@@ -1,0 +1,42 @@
+"""eskf_step_kernel (one launch per predict(+update) step, the Jacobian records handed from the block's pre phase to its
+covariance rounds on chip) against the two kernels it replaces, eskf_pre4_kernel + eskf_cov_rows_kernel.  Both paths
+run the SAME device functions (pre4_body, cov_rows_body) on the same inputs in the same order; only the way the 75-word
+record travels differs (LDS staging rows -> registers instead of memory).  The results must therefore be the same bits:
+state, covariance, status words, through pending injections, zeroed frozen DOFs, non-finite measurements, ragged
+batches, fp32, and for every block size of the one-launch kernel (16 / 32 / 64 instances per block).  The path is
+selected per process (DVI_ESKF_FUSED, DVI_ESKF_FUSED_ROUNDS), so each side runs in a child (tests/_pre4_child.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tmp_path, scenario, tag, **env_over):
+    out = tmp_path / f"{scenario}_{tag}.npz"
+    env = dict(os.environ)
+    for k in ("DVI_ESKF_PRE_LEGACY", "DVI_ESKF_FUSED", "DVI_ESKF_FUSED_ROUNDS"):
+        env.pop(k, None)
+    env.update(env_over)
+    env["DVI_ESKF_VERBOSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_pre4_child.py"), scenario, str(out), ROOT], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert ("eskf_step_kernel" in p.stderr) == (env_over.get("DVI_ESKF_FUSED") == "1"), p.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("scenario", ["unfrozen", "mixed_zeroed", "frozen_hold", "fp32"])
+def test_one_launch_step_equals_the_two_kernels_bit_for_bit(tmp_path, scenario):
+    ref = _run(tmp_path, scenario, "split", DVI_ESKF_FUSED="0")
+    for rounds in ("4", "2", "1"):
+        got = _run(tmp_path, scenario, "fused" + rounds, DVI_ESKF_FUSED="1", DVI_ESKF_FUSED_ROUNDS=rounds)
+        assert set(ref.files) == set(got.files)
+        bad = [k for k in ref.files if not np.array_equal(ref[k], got[k], equal_nan=True)]
+        assert not bad, (scenario, rounds, bad)
+    assert (ref["st1"][[5, 7, 9]] & 2).all()        # the non-finite measurements were flagged (on both sides)

@@ -4,6 +4,6 @@
 reps=$1; shift
 for i in $(seq 1 $reps); do
   for s in "$@"; do
-    env $s python bench.py --no-cpu-baseline --no-streaming 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$s',round(d['value']/1e8,3),round(d['roofline']['kernel_ms'],4),round(d['roofline']['frac_wall'],4),d['all_instances_ok'])"
+    env $s python bench.py --no-cpu-baseline --no-streaming ${AB_ARGS} 2>/dev/null | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$s',round(d['value']/1e8,3),round(d['roofline']['kernel_ms'],4),round(d['roofline']['frac_wall'],4),d['all_instances_ok'])"
   done
 done
