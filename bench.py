@@ -43,6 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BYTES_PER_PAIR_F64 = 5496      # 2*300w + 2*36w + 7w + 8w, w = 8
+LOOP_IN_KERNEL_DEFAULT = False  # see --loop-in-kernel
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
@@ -149,6 +150,10 @@ def main():
     ap.add_argument("--no-streaming", action="store_true", help="skip the secondary measurement at --streaming-batch")
     ap.add_argument("--streaming-batch", type=int, default=262144)
     ap.add_argument("--dump-dofs", default=None, help="rank 0 saves the gathered calibration estimates [B_total,6] (.npy)")
+    ap.add_argument("--loop-in-kernel", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1: every horizon of the timed region is ONE call of dvi_eskf_run_epochs_from (one predict per "
+                         "epoch: one launch of eskf_run_kernel, the time loop in the kernel); 0: one dvi_eskf_step call (one "
+                         "or two launches) per step; -1: the default of this build")
     ap.add_argument("--mode", default="pair", choices=["pair", "predict", "update"],
                     help="diagnostic: time only the predict or only the update launch (not the metric)")
     args = ap.parse_args()
@@ -200,6 +205,7 @@ def main():
 
     from dvi_ekf_amd.workloads import monte_carlo_pairs
     B, H, K, W = args.batch, args.horizon, args.steps, args.warmup
+    LOOP_IN_KERNEL = (args.loop_in_kernel == 1) if args.loop_in_kernel >= 0 else LOOP_IN_KERNEL_DEFAULT
     if args.strong:
         if B % world:
             raise SystemExit("--strong: the total batch must divide evenly over the ranks")
@@ -227,6 +233,8 @@ def main():
                 self.f.set_noise_per_instance(np.tile(np.diag(self.wl.Q), (batch, 1)), np.tile(np.diag(self.wl.R), (batch, 1)))
             self.snap = self.f.clone()
             self.status = torch.zeros(batch, dtype=torch.int32, device=dev)
+            self.status_run = torch.zeros((H, batch), dtype=torch.int32, device=dev)     # (--loop-in-kernel: per epoch)
+            self.ones = np.ones(H, dtype=np.int32)
             self.dofs = torch.empty((batch, 6), dtype=torch.float64, device=dev)
             self.graphs = {}
             self.cal_graph = None
@@ -242,6 +250,18 @@ def main():
             f.step(wl.dt[i], wl.om[i], wl.acc[i], wl.pos[i], wl.quat[i], wl.notch[i], status=self.status)
 
         def eager(self, k0, n):
+            if args.mode == "pair" and LOOP_IN_KERNEL:
+                # horizon after horizon: steps i .. i + m - 1 of a horizon are ONE call (the first one reads the snapshot)
+                k, end = k0, k0 + n
+                wl, f = self.wl, self.f
+                while k < end:
+                    i = k % H
+                    m = min(H - i, end - k)
+                    f.run_epochs(self.ones[:m], wl.dt[i:i + m], wl.om[i:i + m], wl.acc[i:i + m], wl.pos[i:i + m],
+                                 wl.quat[i:i + m], wl.notch[i:i + m], src=self.snap if i == 0 else None,
+                                 status=self.status_run[i:i + m])
+                    k += m
+                return
             for k in range(k0, k0 + n):
                 i = k % H
                 if args.mode == "pair":
@@ -387,7 +407,7 @@ def main():
     torch.cuda.synchronize(dev)
 
     # every instance must have done the full work: no singular / skipped updates, finite state
-    st = status.cpu().numpy()
+    st = (run.status_run if (args.mode == "pair" and LOOP_IN_KERNEL) else status).cpu().numpy()
     x_fin = f.x
     ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
     kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -410,7 +430,7 @@ def main():
         e1.record()
         torch.cuda.synchronize(dev)
         ms = e0.elapsed_time(e1) / nS
-        ok_s = bool((big.status.cpu().numpy() == 0).all())
+        ok_s = bool(((big.status_run if LOOP_IN_KERNEL else big.status).cpu().numpy() == 0).all())
         ach = BYTES_PER_PAIR_F64 * Bs / (ms * 1e-3) / 1e9
         streaming = {"batch": Bs, "steps": nS, "kernel_ms": ms, "pair_steps_per_s": Bs / (ms * 1e-3), "achieved": ach,
                      "frac": ach / HBM_PEAK_GBS, "valid": ok_s,
@@ -505,6 +525,8 @@ def main():
                                  "the first pair-step of a horizon reads the snapshot handle (dvi_eskf_step_from)",
                 "covariance_kernel": "row-resident" if (args.lanes or 1) == 1 else "lds-image, %d lanes/instance" % args.lanes,
                 "hip_graph": graph,
+                "time_loop": "in the kernel: a horizon is one dvi_eskf_run_epochs_from call = one launch of eskf_run_kernel" if LOOP_IN_KERNEL
+                             else "on the host: one dvi_eskf_step call per step",
                 "timed_region": "every one of the %d steps is replayed from a HIP graph (%d graph launch%s)" % (K, len(ops), "" if len(ops) == 1 else "es")
                                 if graph else "steps launched from Python",
                 "untimed_preparation": "%d warm-up steps, graph capture and one launch of every captured graph, then %d replayed steps (%.2f s) to reach sustained clocks"

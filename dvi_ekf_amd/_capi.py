@@ -65,6 +65,7 @@ SIGNATURES = {
     "dvi_eskf_epoch": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_step_from": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "dvi_eskf_run_epochs": (_i, [_vp, C.POINTER(Schedule), _vp]),
+    "dvi_eskf_run_epochs_from": (_i, [_vp, _vp, C.POINTER(Schedule), _vp]),
     "dvi_eskf_get_calibration": (_i, [_vp, _vp, _vp]),
     "dvi_eskf_gather_calibration": (_i, [_vp, _vp, _vp, _vp]),
     "dvi_eskf_flush": (_i, [_vp, _vp]),

@@ -268,12 +268,16 @@ class BatchedESKF:
                     "dvi_eskf_step_from")
         return status, K
 
-    def run_epochs(self, n_pred, dt, om, acc, pos, quat, notch, t_log=None):
+    def run_epochs(self, n_pred, dt, om, acc, pos, quat, notch, t_log=None, src: Optional["BatchedESKF"] = None,
+                   status: Optional[torch.Tensor] = None):
         """A whole run (Filter.run, Filter.py:144-168) enqueued by one call: epoch e = n_pred[e]
         predicts + the update with measurement e.  dt [total] | [total,B]; om/acc [total,3] |
         [total,B,3]; pos [E,3] | [E,B,3]; quat [E,4] | [E,B,4]; notch [E] | [E,B].
         Returns (status [E,B] int32, rows [E,B,30] or None); rows are the trajectory-log rows
-        after every update when their time stamps ``t_log`` [E] are given."""
+        after every update when their time stamps ``t_log`` [E] are given.  ``src``: the first epoch
+        starts from that filter's state (dvi_eskf_run_epochs_from).  ``status``: a caller-owned [E,B]
+        int32 tensor to write the status words into (none is allocated then).  Tensor arguments of the
+        filter's dtype on its device are used as they are."""
         n_pred = np.ascontiguousarray(np.asarray(n_pred, dtype=np.int32))
         E, total = int(n_pred.shape[0]), int(n_pred.sum())
 
@@ -293,7 +297,10 @@ class BatchedESKF:
         if tp.shape != ((E, B, 3) if per else (E, 3)) or tq.shape != ((E, B, 4) if per else (E, 4)) or \
                 tn.shape != ((E, B) if per else (E,)):
             raise ValueError("pos/quat/notch must be [E,3]/[E,4]/[E] or [E,B,3]/[E,B,4]/[E,B]")
-        status = torch.zeros((E, B), dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.zeros((E, B), dtype=torch.int32, device=self.device)
+        elif status.shape != (E, B) or status.dtype != torch.int32 or not status.is_contiguous():
+            raise ValueError("status must be a contiguous int32 [E,B] tensor")
         rows = tl = None
         if t_log is not None:
             tl = np.ascontiguousarray(np.asarray(t_log, dtype=np.float64))
@@ -309,7 +316,10 @@ class BatchedESKF:
         sc.status = _ptr(status)
         sc.t_log = tl.ctypes.data_as(C.POINTER(C.c_double)) if tl is not None else None
         sc.rows_out = _ptr(rows)
-        _capi.check(self.lib.dvi_eskf_run_epochs(self._h, C.byref(sc), self._stream()), "dvi_eskf_run_epochs")
+        if src is not None:
+            _capi.check(self.lib.dvi_eskf_run_epochs_from(self._h, src._h, C.byref(sc), self._stream()), "dvi_eskf_run_epochs_from")
+        else:
+            _capi.check(self.lib.dvi_eskf_run_epochs(self._h, C.byref(sc), self._stream()), "dvi_eskf_run_epochs")
         return status, rows
 
     def gather_calibration(self, rccl_comm, world_size: int) -> torch.Tensor:

@@ -448,7 +448,74 @@ int dvi_eskf_step_from(dvi_eskf* h, dvi_eskf* src, int n_pred, const void* dt, i
     return step_common(h, n_pred, 1, dt, dt_pi, om, acc, imu_pi, pos, quat, notch, meas_pi, K_out, status, stream, src);
 }
 
-int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) {
+}  // extern "C"
+
+namespace {
+// A run whose every epoch is ONE predict + the update (the 1:1 schedule of the saved trajectory and of the Monte-Carlo
+// batches) as ONE launch of eskf_run_kernel: the time loop of Filter.run (Filter.py:144-168) inside the kernel, every
+// block stepping its own instances.  Returns 1 if the run was enqueued that way, 0 if it has to go epoch by epoch
+// (log rows, other schedules, configurations the kernel does not cover, DVI_ESKF_RUN=0), < 0 on error.
+int run_pairs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream) {
+    if (sc->rows_out) return 0;
+    if (sc->n_epochs > 0x7fffffffLL) return 0;
+    for (int64_t e = 0; e < sc->n_epochs; ++e)
+        if (sc->n_pred[e] != 1) return 0;
+    if (src == h) src = nullptr;
+    if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    const size_t es = elem_size(h->dtype);
+    const size_t B = (size_t)h->B;
+    eskf::StepArgs a = base_args(h);
+    a.dt = sc->dt; a.om = sc->om; a.acc = sc->acc;
+    a.pos = sc->pos; a.quat = sc->quat_xyzw; a.notch = sc->notch;
+    a.status = sc->status;
+    a.n_pred = 1;
+    a.do_update = 1;
+    a.dt_stride = sc->dt_per_instance ? 1 : 0;
+    a.imu_stride = sc->imu_per_instance ? 1 : 0;
+    a.meas_stride = sc->meas_per_instance ? 1 : 0;
+    if (!eskf::run_kernel_block(h->dtype, h->lpi, a, h->hp)) return 0;
+    if (stream_is_capturing((hipStream_t)stream)) h->captured = true;
+    a.pending_hint = (h->maybe_pending || h->captured) ? 1 : 0;
+    if (src) {
+        if (flush_pending(src, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+        a.P_src = src->d_P;
+        a.xs_src = src->d_x;
+        a.drop_pending = 1;
+    }
+    eskf::RunArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.n_steps = (int)sc->n_epochs;
+    ra.dt_step = (int64_t)((sc->dt_per_instance ? B : 1) * es);
+    ra.imu_step = (int64_t)((sc->imu_per_instance ? B : 1) * 3 * es);
+    const size_t mrow = sc->meas_per_instance ? B : 1;
+    ra.pos_step = (int64_t)(mrow * 3 * es);
+    ra.quat_step = (int64_t)(mrow * 4 * es);
+    ra.notch_step = (int64_t)(mrow * es);
+    ra.status_step = (int64_t)B;
+    if (eskf::launch_run(h->dtype, h->lpi, a, ra, h->hp, (hipStream_t)stream) != hipSuccess) return DVI_ESKF_EHIP;
+    h->maybe_pending = true;        // the last step's update leaves its error state behind
+    h->jac_ip = -1;
+    return 1;
+}
+
+int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream);
+}  // namespace
+
+extern "C" {
+
+int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) { return run_epochs_impl(h, nullptr, sc, stream); }
+
+int dvi_eskf_run_epochs_from(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream) {
+    if (!src) return DVI_ESKF_EINVAL;
+    return run_epochs_impl(h, src, sc, stream);
+}
+
+}  // extern "C"
+
+namespace {
+int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream) {
     if (!h || !sc || sc->n_epochs < 0) return DVI_ESKF_EINVAL;
     if (sc->n_epochs == 0) return DVI_ESKF_OK;
     if (!sc->n_pred || !sc->pos || !sc->quat_xyzw || !sc->notch) return DVI_ESKF_EINVAL;
@@ -459,6 +526,9 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
         total += sc->n_pred[e];
     }
     if (total > 0 && (!sc->dt || !sc->om || !sc->acc)) return DVI_ESKF_EINVAL;
+    if (src == h) src = nullptr;
+    if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
+    if (int one = run_pairs_in_one_launch(h, src, sc, stream)) return one < 0 ? one : DVI_ESKF_OK;
     {   // size the Jacobian workspace for the longest epoch once, not epoch by epoch
         int longest = 0;
         for (int64_t e = 0; e < sc->n_epochs; ++e) longest = sc->n_pred[e] > longest ? sc->n_pred[e] : longest;
@@ -486,7 +556,7 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
     // (measured, config #5's schedule, us per camera frame, one stream -> two: B = 1 024 72 -> 75 fp32 / 80 -> 82 fp64; 2 048
     //  78 -> 79 / 98 -> 86; 4 096 100 -> 83 / 115 -> 106; 8 192 129 -> 114 / 148 -> 146; 16 384 184 -> 167 / 256 -> 246)
     static const int64_t two_streams_min = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)2048; }();
-    bool split = two_streams && eskf::epoch_sub_batches_available() && h->lpi == 1 && !h->d_noise && !sc->rows_out &&
+    bool split = !src && two_streams && eskf::epoch_sub_batches_available() && h->lpi == 1 && !h->d_noise && !sc->rows_out &&
                  (h->B % 128) == 0 && h->B >= two_streams_min && h->B <= two_streams_max && sc->n_epochs >= 2;
     for (int64_t e = 0; e < sc->n_epochs && split; ++e) split = sc->n_pred[e] >= 2;
     if (split) {
@@ -521,7 +591,7 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
         int rc = step_common(h, n, 1, n ? dt + off * dt_row : nullptr, sc->dt_per_instance, n ? om + off * imu_row : nullptr,
                              n ? acc + off * imu_row : nullptr, sc->imu_per_instance, pos + (size_t)e * mrow * 3 * es,
                              quat + (size_t)e * mrow * 4 * es, notch + (size_t)e * mrow * es, sc->meas_per_instance,
-                             nullptr, sc->status ? sc->status + (size_t)e * B : nullptr, stream);
+                             nullptr, sc->status ? sc->status + (size_t)e * B : nullptr, stream, e == 0 ? src : nullptr);
         if (rc != DVI_ESKF_OK) return rc;
         if (sc->rows_out) {
             rc = dvi_eskf_log_rows(h, sc->t_log[e], static_cast<char*>(sc->rows_out) + (size_t)e * B * 30 * es, stream);
@@ -531,6 +601,9 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sc, void* stream) 
     }
     return DVI_ESKF_OK;
 }
+}  // namespace
+
+extern "C" {
 
 namespace {
 // RCCL is bound at first use: the library must call into the SAME RCCL image that made the

@@ -93,6 +93,22 @@ struct StepArgs {
     int64_t sub_first, sub_count;
 };
 
+// A run of n_steps consecutive predict(+update) steps in ONE launch (eskf_run_kernel): the StepArgs describe step 0, the
+// inputs of step k lie k strides further on (bytes; 0 = the same sample for every step), the caller's status words of
+// step k at status + k * status_step (elements).  From step 1 on the step reads the handle's own P / xs.
+struct RunArgs {
+    int n_steps, pad;
+    int64_t dt_step, imu_step, pos_step, quat_step, notch_step;
+    int64_t status_step;
+};
+// whether launch_run would take this run (same coverage as the one-launch step: one predict per step, shared noise
+// model, default covariance kernel, no gain output, no kept Jacobians); 0 = no, else instances per block
+int run_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp);
+// the one-launch step (eskf_step_kernel): instances per block if it takes this launch, else 0; and its launcher
+int step_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp);
+hipError_t launch_step_fused(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
+hipError_t launch_run(int dtype, int lpi, const StepArgs& a, const RunArgs& ra, const HostParams& hp, hipStream_t stream);
+
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 bool epoch_sub_batches_available();

@@ -919,7 +919,7 @@ __device__ __forceinline__ void jac_blocks_attitude(const DevParams<T>& prm, con
 // q1..q3 only differ from the nominal ones where a frozen DOF is zeroed (then sin = 0, cos = 1 exactly),
 // phi+ = q3+ - (theta + dt theta') gets its own evaluation unless it equals phi.
 // ----------------------------------------------------------------------------------
-#ifdef ESKF_X_STAMPS        // diagnostic build only: wall-clock stamps (100 MHz) of every block of the last pre4 launch
+#if defined(ESKF_X_STAMPS) && !defined(ESKF_TU_FUSED)   // diagnostic build only: wall-clock stamps (100 MHz) of every block of the last pre4 launch
 __device__ unsigned long long g_x_stamps[8 * 4096];
 __device__ unsigned long long g_c_stamps[8 * 4096];      // covariance kernel: every eighth block
 hipError_t x_read_cstamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_c_stamps), sizeof(g_c_stamps)); }
@@ -930,6 +930,50 @@ hipError_t x_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(o
 #define ESKF_STAMP(K) {}
 #define ESKF_CSTAMP(K) {}
 #endif
+// The kernel's own arguments as they lie in the kernarg segment (constant address space).  A wavefront of
+// eskf_step_kernel that works through several pairs re-reads what it needs from there at three points of every round
+// (cov_rows_body<WAVE>::refresh_args) through a pointer the compiler cannot see through: 106 dwords of arguments are more
+// than a wavefront has scalar registers, and read once in front of the round loop they are all kept live across it --
+// what does not fit is parked in lanes of vector registers, 260 v_readlane / v_writelane per round (a third on top of
+// the round's own vector instructions; measured on the first build of that kernel).
+template <typename T>
+struct StepKernArgs { StepArgs a; DevParams<T> prm; };
+template <typename T>
+struct RunKernArgs { StepArgs a; DevParams<T> prm; RunArgs ra; };     // eskf_run_kernel: the same two, then the run
+template <typename S>
+__device__ __forceinline__ S load_kernarg(const char __attribute__((address_space(4))) * p) {
+    static_assert(sizeof(S) % 4 == 0, "whole dwords");
+    S r;
+    const uint32_t __attribute__((address_space(4))) * w = (const uint32_t __attribute__((address_space(4))) *)p;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(S) / 4; ++i) reinterpret_cast<uint32_t*>(&r)[i] = w[i];
+    return r;
+}
+// eskf_run_kernel: the arguments of step k of the run -- inputs moved on by k strides; from the second step on the step
+// is in place and injects what the step before left behind
+template <typename T>
+__device__ __forceinline__ void load_run_step_args(int k, StepArgs& a, DevParams<T>& prm) {
+    const char __attribute__((address_space(4))) * ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    a = load_kernarg<StepArgs>(ka + offsetof(RunKernArgs<T>, a));
+    prm = load_kernarg<DevParams<T>>(ka + offsetof(RunKernArgs<T>, prm));
+    const RunArgs ra = load_kernarg<RunArgs>(ka + offsetof(RunKernArgs<T>, ra));
+    a.dt = reinterpret_cast<const char*>(a.dt) + (int64_t)k * ra.dt_step;
+    a.om = reinterpret_cast<const char*>(a.om) + (int64_t)k * ra.imu_step;
+    a.acc = reinterpret_cast<const char*>(a.acc) + (int64_t)k * ra.imu_step;
+    if (a.do_update) {
+        a.pos = reinterpret_cast<const char*>(a.pos) + (int64_t)k * ra.pos_step;
+        a.quat = reinterpret_cast<const char*>(a.quat) + (int64_t)k * ra.quat_step;
+        a.notch = reinterpret_cast<const char*>(a.notch) + (int64_t)k * ra.notch_step;
+        if (a.status) a.status += (int64_t)k * ra.status_step;
+    }
+    if (k > 0) {
+        a.P_src = a.P;
+        a.xs_src = a.xs;
+        a.drop_pending = 0;
+        a.pending_hint = a.do_update ? 1 : a.pending_hint;
+    }
+}
 // exchange words of a lane sit in its own staging row, on block words that are only written after barrier 1b
 constexpr int PRE4_XOFF = J_BM;
 template <typename T>
@@ -945,6 +989,9 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
 // the covariance rounds of the same block take them from there; nothing is written to a.J.
 template <typename T, bool KEEP = false, int NI = 64>
 __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock) {
+    // (No re-reading of the arguments from the kernarg segment in here, as the covariance body does: tried for the run
+    //  kernel, it changed where the compiler contracts a*b+c in the chains -- one ulp in x after one step -- and with
+    //  MachineLICM off for these kernels it is not needed.)
     T* sJ = reinterpret_cast<T*>(smem_raw);
     const int JS = (!KEEP && prm.jfull) ? J_FULL : J_CORE;   // staging rows = whole records: residual words, then the blocks (odd: conflict-free)
     const int lane = threadIdx.x & 63;
@@ -955,7 +1002,6 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
     const int64_t b_last = (b0 + NI - 1 < a.B) ? b0 + NI - 1 : a.B - 1;
     const int64_t b = live ? b_raw : b_last;           // tail lanes recompute the block's last instance, write nothing
     const T* xi = reinterpret_cast<const T*>(a.xs_src);
-    T* xo = reinterpret_cast<T*>(a.xs);
     const int64_t B = a.B;
 #ifdef ESKF_X_STAGGER       // experiment: every other block starts ESKF_X_STAGGER x 0.5 us late
     if (vblock & 1) {
@@ -1055,6 +1101,8 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
             pc[i] = pc[i] + dt * vi + dt * Rcr[i];                                  // equations.py:83-85
             rp[i] = gpos[i] - pc[i];                                                // Filter.py:369
         }
+        T* xo = reinterpret_cast<T*>(a.xs);
+        const int64_t Bo = a.B;
         if (a.do_update) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) row[J_RES + i] = rp[i];
@@ -1065,11 +1113,11 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
         if (live) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                xo[(0 + i) * B + b] = p[i]; xo[(3 + i) * B + b] = v[i]; xo[(19 + i) * B + b] = pc[i];
-                xo[(26 + i) * B + b] = om_n[i]; xo[(29 + i) * B + b] = acc_n[i];    // Filter.py:225-227
+                xo[(0 + i) * Bo + b] = p[i]; xo[(3 + i) * Bo + b] = v[i]; xo[(19 + i) * Bo + b] = pc[i];
+                xo[(26 + i) * Bo + b] = om_n[i]; xo[(29 + i) * Bo + b] = acc_n[i];    // Filter.py:225-227
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { xo[(6 + i) * B + b] = qn[i]; xo[(32 + i) * B + b] = qn[i]; }
+            for (int i = 0; i < 4; ++i) { xo[(6 + i) * Bo + b] = qn[i]; xo[(32 + i) * Bo + b] = qn[i]; }
         }
     } else if (role == 1) {
         // ---- W1: camera attitude, notch states, rotation and notch residuals -------------------------------
@@ -1149,11 +1197,13 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
             for (int i = 0; i < 3; ++i) r[i] = f * qe[i];
             r[3] = ang_notch - notch[0];
         }
+        T* xo = reinterpret_cast<T*>(a.xs);
+        const int64_t Bo = a.B;
         if (live) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) xo[(16 + i) * B + b] = notch[i];
+            for (int i = 0; i < 3; ++i) xo[(16 + i) * Bo + b] = notch[i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xo[(22 + i) * B + b] = qcn[i];
+            for (int i = 0; i < 4; ++i) xo[(22 + i) * Bo + b] = qcn[i];
         }
         if (a.do_update) {
 #pragma unroll
@@ -1235,9 +1285,11 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #pragma unroll
         for (int i = 0; i < 3; ++i) om_t[i] = om_o[i] - sig_om[i];
         if (role == 2) {
+            T* xo = reinterpret_cast<T*>(a.xs);
+            const int64_t Bo = a.B;
             if (live) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) xo[(10 + i) * B + b] = dofs[i];
+                for (int i = 0; i < 6; ++i) xo[(10 + i) * Bo + b] = dofs[i];
             }
             jac_blocks_position(prm, t, dofs, om_t, Ro, dt, J);
         } else {
@@ -2851,23 +2903,6 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 // compiler has to be kept from moving them across), the region is the 600-word image alone, and the first predict's
 // record comes from the registers `jpre` (words lig, 32 + lig, 64 + lig of the record the block's pre phase left in LDS)
 // instead of from a.J.
-// The kernel's own arguments as they lie in the kernarg segment (constant address space).  A wavefront of
-// eskf_step_kernel that works through several pairs re-reads what it needs from there at three points of every round
-// (cov_rows_body<WAVE>::refresh_args) through a pointer the compiler cannot see through: 106 dwords of arguments are more
-// than a wavefront has scalar registers, and read once in front of the round loop they are all kept live across it --
-// what does not fit is parked in lanes of vector registers, 260 v_readlane / v_writelane per round (a third on top of
-// the round's own vector instructions; measured on the first build of that kernel).
-template <typename T>
-struct StepKernArgs { StepArgs a; DevParams<T> prm; };
-template <typename S>
-__device__ __forceinline__ S load_kernarg(const char __attribute__((address_space(4))) * p) {
-    static_assert(sizeof(S) % 4 == 0, "whole dwords");
-    S r;
-    const uint32_t __attribute__((address_space(4))) * w = (const uint32_t __attribute__((address_space(4))) *)p;
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(S) / 4; ++i) reinterpret_cast<uint32_t*>(&r)[i] = w[i];
-    return r;
-}
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2875,16 +2910,23 @@ __device__ __forceinline__ void wave_sync() {
 }
 template <typename T, bool PIN, int LPI, bool SLIM, bool WAVE = false>
 __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevParams<T>& prm_in, T* smem, const int vblock, const int lane,
-                                              const T* jpre = nullptr) {
+                                              const T* jpre = nullptr, const int kstep = -1) {
     StepArgs a = a_in;
     DevParams<T> prm = prm_in;
-    // WAVE: the arguments as of now, straight from the kernarg segment (see StepKernArgs); whatever was read before is dead
+    // WAVE: the arguments as of now, straight from the kernarg segment (see StepKernArgs); whatever was read before is dead.
+    // kstep >= 0 (eskf_run_kernel): this is step kstep of a run -- from step 1 on the step is in place, and the caller's
+    // status words of the step lie kstep strides further on.
     auto refresh_args = [&]() {
         if constexpr (WAVE) {
             const char __attribute__((address_space(4))) * ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             a = load_kernarg<StepArgs>(ka + offsetof(StepKernArgs<T>, a));
             prm = load_kernarg<DevParams<T>>(ka + offsetof(StepKernArgs<T>, prm));
+            if (kstep >= 0) {
+                const RunArgs ra = load_kernarg<RunArgs>(ka + offsetof(RunKernArgs<T>, ra));
+                if (kstep > 0) { a.P_src = a.P; a.xs_src = a.xs; }
+                if (a.status) a.status += (int64_t)kstep * ra.status_step;
+            }
         }
     };
     refresh_args();
@@ -3550,16 +3592,14 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 // Not covered (the launcher falls back to the two kernels): per-instance noise, a gyro block in Q or kept Jacobians
 // (85-word records), gain output, launches over a part of the batch, epochs.
 // ----------------------------------------------------------------------------------
+// One step of a block: phase 1, hand-over, rounds (see above).  kstep: -1 = the launch is this one step (eskf_step_kernel),
+// else the step's number in the run (eskf_run_kernel).
 template <typename T, int ROUNDS>
-__global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
+__device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int wave,
+                                           const int lane, const int kstep) {
     constexpr int NI = 16 * ROUNDS;
     constexpr int WREGION = 2 * 600;                     // words per wavefront: the images of its two instances
     static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // (the wavefront's number as a SCALAR: everything derived from it -- the role, the image address, the pair index and
-    //  with it the wave-uniform bases of the covariance body's addressing -- stays in scalar registers)
-    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int lane = (int)threadIdx.x & 63;
     // ---- phase 1
     if (wave < 4) {
         pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x);
@@ -3600,11 +3640,58 @@ __global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams
         //  round instead of being hoisted out of the loop and spilled across it)
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
-        cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0);
+        cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep);
 #pragma unroll
         for (int q = 0; q + 1 < ROUNDS; ++q)
 #pragma unroll
             for (int k = 0; k < 3; ++k) jr[q][k] = jr[q + 1][k];
+    }
+}
+
+template <typename T, int ROUNDS>
+__global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // (the wavefront's number as a SCALAR: everything derived from it -- the role, the image address, the pair index and
+    //  with it the wave-uniform bases of the covariance body's addressing -- stays in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    step_block<T, ROUNDS>(a, prm, smem_raw, wave, lane, -1);
+}
+
+// ----------------------------------------------------------------------------------
+// eskf_run_kernel: the time loop in the kernel (Filter.run, Filter.py:144-168, for a schedule of one IMU sample per
+// camera frame: the 1:1 schedule of the saved trajectory and of the Monte-Carlo batches).  A block keeps ITS instances
+// for the whole run and steps them n_steps times: instances are independent, so no block ever waits for another -- the
+// only synchronisation is the block's own barrier between a step's covariance rounds (error state, status words) and the
+// next step's pre phase, which injects them.  Per step the same code as eskf_step_kernel (same bits as n_steps launches);
+// what the run saves on top is the launch boundary per step, and blocks that drift apart run one block's pre phase next
+// to its neighbour's rounds.  P still round-trips memory every step (64 x 2.4 KB per block do not fit a CU).
+// ----------------------------------------------------------------------------------
+// One step of the run.  (Inlined into the time loop -- which is only affordable because this translation unit is
+// compiled without MachineLICM, see "host-side launchers": with the pass everything the step materialises is hoisted in
+// front of the time loop and spilled across it.  As a real function call the step costs the callee-saved registers'
+// round trip through scratch: 100 KB per block and step.)
+typedef unsigned char __attribute__((address_space(3))) * lds_bytes_t;
+template <typename T, int ROUNDS>
+__device__ __forceinline__ void run_one_step(lds_bytes_t smem_lds, const int wave, const int lane, const int k) {
+    unsigned char* smem_raw = (unsigned char*)smem_lds;
+    StepArgs a;
+    DevParams<T> prm;
+    load_run_step_args<T>(k, a, prm);
+    step_block<T, ROUNDS>(a, prm, smem_raw, wave, lane, k);
+}
+template <typename T, int ROUNDS>
+__global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams<T> prm0, RunArgs ra0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    const int n_steps = ra0.n_steps;
+#pragma unroll 1
+    for (int k = 0; k < n_steps; ++k) {
+        run_one_step<T, ROUNDS>((lds_bytes_t)smem_raw, wave, lane, k);
+        // error states and status words of this step are visible to the pre phase of the next (and the images are free
+        // to become staging rows again)
+        __syncthreads();
     }
 }
 
@@ -3890,7 +3977,17 @@ __global__ __launch_bounds__(256) void eskf_jacobians_kernel(int64_t B, const T*
 
 // ----------------------------------------------------------------------------------
 // host-side launchers
+//
+// This file is compiled TWICE (Makefile): as it is -- every kernel and launcher except the one-launch step and the run
+// kernel -- and with -DESKF_TU_FUSED -mllvm -disable-machine-licm, which leaves only those two and their launchers.  In
+// eskf_step_kernel / eskf_run_kernel the covariance body sits inside a loop over rounds (and that inside the time loop):
+// MachineLICM hoists every constant the body materialises -- the polynomial coefficients of sincos / asin, the lane-mask
+// constants, forty vector and sixty scalar registers of them -- in front of the loop, keeps them live across it and
+// spills what does not fit (run kernel: 73 vector / 160 scalar registers spilled with it, 21 / 0 without; a step of
+// the run was slower than a launch per step).  The other kernels keep the pass: their loops over the predicts of an
+// epoch are what it is for.
 // ----------------------------------------------------------------------------------
+#ifndef ESKF_TU_FUSED
 template <typename T, int LPI, bool PIN = false>
 static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
@@ -3923,11 +4020,13 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     return hipGetLastError();
 }
 
+#endif  // !ESKF_TU_FUSED
+
 // diagnostic switch (environment DVI_ESKF_PRE_LEGACY=1, read once): single-predict launches through the two-role
 // pre kernel instead of eskf_pre4_kernel -- the A/B of the two and the bitwise test of one against the other
 static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEGACY"); return e && e[0] == '1'; }();
-// largest batch whose epochs go through eskf_nominal_kernel + eskf_jac_kernel (DVI_ESKF_EPOCH_SPLIT_MAX; -1 = always)
-static const int64_t g_epoch_split_max = []() { const char* e = getenv("DVI_ESKF_EPOCH_SPLIT_MAX"); return e ? (int64_t)atoll(e) : (int64_t)40960; }();
+
+#ifdef ESKF_TU_FUSED
 
 // The one-launch step (eskf_step_kernel).  DVI_ESKF_FUSED=0 switches it off, =1 forces it wherever it is able to run
 // (A/B against the two kernels, and the bitwise test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1|2|4 pins
@@ -3984,10 +4083,67 @@ static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm,
     return hipGetLastError();
 }
 
+// The run kernel takes what the one-launch step takes; its block size follows the same table unless DVI_ESKF_RUN_ROUNDS
+// pins it (DVI_ESKF_RUN=0: runs are enqueued step by step)
+static const int g_run = []() { const char* e = getenv("DVI_ESKF_RUN"); return e ? atoi(e) : -1; }();
+static const int g_run_rounds = []() { const char* e = getenv("DVI_ESKF_RUN_ROUNDS"); return e ? atoi(e) : 0; }();
+static int run_kernel_rounds(int64_t B) {
+    if (g_run == 0) return 0;
+    if (g_run_rounds == 1 || g_run_rounds == 2 || g_run_rounds == 4) return g_run_rounds;
+    if (B <= 12288) return 1;
+    if (B <= 24576) return 2;
+    return 4;
+}
+template <typename T>
+static int run_kernel_block_typed(int lpi, const StepArgs& a, const DevParams<T>& prm) {
+    static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 600 * sizeof(double));
+    const int rounds = run_kernel_rounds(a.B);
+    const bool ok = lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count &&
+                    !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
+    return ok ? 16 * rounds : 0;
+}
+int run_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
+    if (dtype == 0) return run_kernel_block_typed<double>(lpi, a, make_dev_params<double>(hp));
+    return run_kernel_block_typed<float>(lpi, a, make_dev_params<float>(hp));
+}
+template <typename T>
+static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra, const DevParams<T>& prm, hipStream_t stream) {
+    const int ni = run_kernel_block_typed<T>(lpi, a, prm);
+    if (!ni || ra.n_steps < 1) return hipErrorInvalidValue;
+    const size_t lds = (size_t)8 * 2 * 600 * sizeof(T);
+    const unsigned blocks = (unsigned)((a.B + ni - 1) / ni);
+    static const bool verbose = []() { const char* e = getenv("DVI_ESKF_VERBOSE"); return e && e[0] == '1'; }();
+    static bool said = false;
+    if (verbose && !said) {
+        said = true;
+        fprintf(stderr, "dvi_eskf: runs of pair steps go through eskf_run_kernel (%d instances per block)\n", ni);
+    }
+    if (ni == 64) hipLaunchKernelGGL((eskf_run_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm, ra);
+    else if (ni == 32) hipLaunchKernelGGL((eskf_run_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm, ra);
+    else hipLaunchKernelGGL((eskf_run_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm, ra);
+    return hipGetLastError();
+}
+hipError_t launch_run(int dtype, int lpi, const StepArgs& a, const RunArgs& ra, const HostParams& hp, hipStream_t stream) {
+    if (dtype == 0) return launch_run_typed<double>(lpi, a, ra, make_dev_params<double>(hp), stream);
+    return launch_run_typed<float>(lpi, a, ra, make_dev_params<float>(hp), stream);
+}
+int step_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
+    const bool ok = dtype == 0 ? step_kernel_covers(lpi, a, make_dev_params<double>(hp)) : step_kernel_covers(lpi, a, make_dev_params<float>(hp));
+    return ok ? 16 * step_kernel_rounds(a.B) : 0;
+}
+hipError_t launch_step_fused(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
+    if (dtype == 0) return launch_step_kernel<double>(a, make_dev_params<double>(hp), stream);
+    return launch_step_kernel<float>(a, make_dev_params<float>(hp), stream);
+}
+
+#else   // !ESKF_TU_FUSED
+
+// largest batch whose epochs go through eskf_nominal_kernel + eskf_jac_kernel (DVI_ESKF_EPOCH_SPLIT_MAX; -1 = always)
+static const int64_t g_epoch_split_max = []() { const char* e = getenv("DVI_ESKF_EPOCH_SPLIT_MAX"); return e ? (int64_t)atoll(e) : (int64_t)40960; }();
+
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
-    if (step_kernel_covers(lpi, a, prm)) return launch_step_kernel<T>(a, prm, stream);
     // a part of the batch: only the kernels that honour sub_first / sub_count (the host asks for it under these conditions only)
     if (a.sub_count && (a.n_pred < 2 || g_pre_legacy || !a.aux || a.noise || a.K_out || lpi != 1 || (a.sub_count & 63) || (a.sub_first & 63)))
         return hipErrorInvalidValue;
@@ -4066,6 +4222,7 @@ hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipS
 }
 
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
+    if (a.B > 0 && step_kernel_block(dtype, lpi, a, hp)) return launch_step_fused(dtype, a, hp, stream);     // the one-launch step
     if (dtype == 0) return launch_step_typed<double>(lpi, a, make_dev_params<double>(hp), stream);
     return launch_step_typed<float>(lpi, a, make_dev_params<float>(hp), stream);
 }
@@ -4179,5 +4336,7 @@ hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void*
         hipLaunchKernelGGL(eskf_log_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)xs, (float)t, (float*)rows);
     return hipGetLastError();
 }
+
+#endif  // !ESKF_TU_FUSED
 
 }  // namespace eskf

@@ -194,6 +194,16 @@ typedef struct dvi_eskf_schedule {
  * then run next to the other half's covariance kernel.  Instances do not interact: the results are bit for bit those
  * of the one-stream order, and the call stays capturable. */
 int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sched, void* stream);
+/* A run whose every epoch is one predict + the update (n_pred[e] == 1 throughout: the 1:1 schedule of the reference's
+ * saved trajectory, kf_best_mandala0_mono.txt, and of the Monte-Carlo batches), no log rows, shared noise model, default
+ * covariance kernel, is ONE launch: the time loop of Filter.run (Filter.py:144-168) runs inside the kernel
+ * (eskf_run_kernel), every thread block stepping its own instances from frame to frame; results are bit for bit those of
+ * the epoch-by-epoch calls.  Capturable like any other call. */
+
+/* dvi_eskf_run_epochs whose first epoch starts from the (flushed) state of `src`, as dvi_eskf_step_from does for one
+ * step: h == copy_state(src) followed by run_epochs, bit for bit, without the copy.  src != NULL; same batch, dtype
+ * and device as h. */
+int dvi_eskf_run_epochs_from(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sched, void* stream);
 
 /* The estimated calibration parameters, i.e. state.dofs (Filter.calculate_dof_metric,
  * Filter.py:452-455): dofs_out [B,6]. */

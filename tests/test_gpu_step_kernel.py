@@ -40,3 +40,20 @@ def test_one_launch_step_equals_the_two_kernels_bit_for_bit(tmp_path, scenario):
         bad = [k for k in ref.files if not np.array_equal(ref[k], got[k], equal_nan=True)]
         assert not bad, (scenario, rounds, bad)
     assert (ref["st1"][[5, 7, 9]] & 2).all()        # the non-finite measurements were flagged (on both sides)
+
+
+@pytest.mark.parametrize("batch,dtype,rounds", [(777, "f64", "1"), (777, "f64", "4"), (1500, "f64", "2"), (515, "f32", "4"),
+                                                (2048, "f64", "")])
+def test_run_in_one_launch_equals_the_steps_one_by_one(batch, dtype, rounds):
+    """dvi_eskf_run_epochs with one predict per epoch is one launch of eskf_run_kernel (the time loop in the kernel):
+    bit for bit the step-by-step run, also started from another handle's state, continued, and with shared streams."""
+    env = dict(os.environ)
+    for k in ("DVI_ESKF_PRE_LEGACY", "DVI_ESKF_FUSED", "DVI_ESKF_FUSED_ROUNDS", "DVI_ESKF_RUN", "DVI_ESKF_RUN_ROUNDS"):
+        env.pop(k, None)
+    if rounds:
+        env["DVI_ESKF_RUN_ROUNDS"] = rounds
+    env["DVI_ESKF_VERBOSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_run_child.py"), str(batch), dtype, ROOT], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "eskf_run_kernel" in p.stderr, p.stderr[-2000:]
