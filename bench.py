@@ -43,7 +43,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BYTES_PER_PAIR_F64 = 5496      # 2*300w + 2*36w + 7w + 8w, w = 8
-LOOP_IN_KERNEL_DEFAULT = False  # see --loop-in-kernel
+LOOP_IN_KERNEL_DEFAULT = True   # see --loop-in-kernel
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 

@@ -556,34 +556,51 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
     // (measured, config #5's schedule, us per camera frame, one stream -> two: B = 1 024 72 -> 75 fp32 / 80 -> 82 fp64; 2 048
     //  78 -> 79 / 98 -> 86; 4 096 100 -> 83 / 115 -> 106; 8 192 129 -> 114 / 148 -> 146; 16 384 184 -> 167 / 256 -> 246)
     static const int64_t two_streams_min = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)2048; }();
-    bool split = !src && two_streams && eskf::epoch_sub_batches_available() && h->lpi == 1 && !h->d_noise && !sc->rows_out &&
-                 (h->B % 128) == 0 && h->B >= two_streams_min && h->B <= two_streams_max && sc->n_epochs >= 2;
-    for (int64_t e = 0; e < sc->n_epochs && split; ++e) split = sc->n_pred[e] >= 2;
+    int shortest = 0x7fffffff;
+    for (int64_t e = 0; e < sc->n_epochs; ++e) shortest = sc->n_pred[e] < shortest ? sc->n_pred[e] : shortest;
+    // (whether the kernels can run a half of the batch: asked where the launcher decides it, eskf_kernels.hip)
+    const bool split = !src && two_streams && !sc->rows_out && (h->B % 128) == 0 && h->B >= two_streams_min && h->B <= two_streams_max &&
+                       sc->n_epochs >= 2 &&
+                       eskf::epoch_sub_batches_ok(h->lpi, h->B / 2, h->B / 2, shortest, h->d_noise != nullptr, false, h->d_aux != nullptr);
     if (split) {
         DeviceGuard g(h->device);
         hipStream_t cs = (hipStream_t)stream;
         if (!g.ok || !ensure_side_streams(h)) return DVI_ESKF_EHIP;
-        if (hipEventRecord(h->ev_fork, cs) != hipSuccess) return DVI_ESKF_EHIP;
+        if (hipEventRecord(h->ev_fork, cs) != hipSuccess) return DVI_ESKF_EHIP;     // (nothing forked yet: nothing to join)
         const int64_t half = h->B / 2;
-        for (int s2 = 0; s2 < 2; ++s2)
-            if (hipStreamWaitEvent(h->side[s2], h->ev_fork, 0) != hipSuccess) return DVI_ESKF_EHIP;
+        // From here on EVERY exit goes through the join below: a side stream that has been made to wait for the fork
+        // event holds work that is unordered with respect to `stream` (and, under capture, belongs to the capture: an
+        // unjoined stream makes hipStreamEndCapture fail) until `stream` waits for its join event.  The first error is
+        // what the call returns.
+        int rc_first = DVI_ESKF_OK;
+        bool forked[2] = {false, false};
+        for (int s2 = 0; s2 < 2 && rc_first == DVI_ESKF_OK; ++s2) {
+            if (hipStreamWaitEvent(h->side[s2], h->ev_fork, 0) != hipSuccess) rc_first = DVI_ESKF_EHIP;
+            else forked[s2] = true;
+        }
+        // (test hook, tests/test_gpu_capi.py: DVI_ESKF_TEST_FAIL_SPLIT_EPOCH=<e> makes the enqueue of epoch e fail)
+        const char* fail_env = getenv("DVI_ESKF_TEST_FAIL_SPLIT_EPOCH");
+        const int64_t fail_epoch = fail_env ? (int64_t)atoll(fail_env) : -1;
         size_t off2 = 0;
-        for (int64_t e = 0; e < sc->n_epochs; ++e) {        // (enqueued epoch by epoch, alternating: both queues always have work)
+        for (int64_t e = 0; e < sc->n_epochs && rc_first == DVI_ESKF_OK; ++e) {     // (enqueued epoch by epoch, alternating: both queues always have work)
             const int n = sc->n_pred[e];
-            for (int s2 = 0; s2 < 2; ++s2) {
-                int rc = step_common(h, n, 1, dt + off2 * dt_row, sc->dt_per_instance, om + off2 * imu_row, acc + off2 * imu_row,
-                                     sc->imu_per_instance, pos + (size_t)e * mrow * 3 * es, quat + (size_t)e * mrow * 4 * es,
-                                     notch + (size_t)e * mrow * es, sc->meas_per_instance, nullptr,
-                                     sc->status ? sc->status + (size_t)e * B : nullptr, h->side[s2], nullptr, s2 * half, half);
-                if (rc != DVI_ESKF_OK) return rc;
+            for (int s2 = 0; s2 < 2 && rc_first == DVI_ESKF_OK; ++s2) {
+                if (e == fail_epoch && s2 == 1) { rc_first = DVI_ESKF_EHIP; break; }
+                rc_first = step_common(h, n, 1, dt + off2 * dt_row, sc->dt_per_instance, om + off2 * imu_row, acc + off2 * imu_row,
+                                       sc->imu_per_instance, pos + (size_t)e * mrow * 3 * es, quat + (size_t)e * mrow * 4 * es,
+                                       notch + (size_t)e * mrow * es, sc->meas_per_instance, nullptr,
+                                       sc->status ? sc->status + (size_t)e * B : nullptr, h->side[s2], nullptr, s2 * half, half);
             }
             off2 += (size_t)n;
         }
-        for (int s2 = 0; s2 < 2; ++s2)
-            if (hipEventRecord(h->ev_join[s2], h->side[s2]) != hipSuccess || hipStreamWaitEvent(cs, h->ev_join[s2], 0) != hipSuccess)
-                return DVI_ESKF_EHIP;
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (!forked[s2]) continue;
+            if (hipEventRecord(h->ev_join[s2], h->side[s2]) != hipSuccess || hipStreamWaitEvent(cs, h->ev_join[s2], 0) != hipSuccess) {
+                if (rc_first == DVI_ESKF_OK) rc_first = DVI_ESKF_EHIP;
+            }
+        }
         if (stream_is_capturing(cs)) h->captured = true;
-        return DVI_ESKF_OK;
+        return rc_first;
     }
     size_t off = 0;
     for (int64_t e = 0; e < sc->n_epochs; ++e) {

@@ -3602,7 +3602,11 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
     static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
     // ---- phase 1
     if (wave < 4) {
+        // (the pre phase is what the block's eight wavefronts wait for: its four chains go first on their SIMDs, next to
+        //  the other block's rounds -- same-box A/B of the run kernel: +1 % at B = 65 536, +5.5 % at 8 192)
+        __builtin_amdgcn_s_setprio(2);
         pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x);
+        __builtin_amdgcn_s_setprio(0);
     } else {
         __syncthreads();                                // barrier 1
         __syncthreads();                                // barrier 1b
@@ -3686,6 +3690,11 @@ __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
     const int n_steps = ra0.n_steps;
+    // (experiment, DVI_ESKF_RUN_STAGGER=<us>: every other group of 256 blocks starts late, so that the two blocks of a CU
+    //  are not in their pre phases at the same time)
+    if (ra0.pad > 0 && (((int)blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < ra0.pad; ++i) __builtin_amdgcn_s_sleep(37);     // 37 x 64 clocks ~ 1 us
+    }
 #pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
         run_one_step<T, ROUNDS>((lds_bytes_t)smem_raw, wave, lane, k);
@@ -3991,6 +4000,7 @@ __global__ __launch_bounds__(256) void eskf_jacobians_kernel(int64_t B, const T*
 template <typename T, int LPI, bool PIN = false>
 static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
+    if (a.sub_count) return hipErrorInvalidValue;          // (the LDS-image kernel covers the whole batch)
     // rounds per wave: enough waves to keep every CU's LDS full several times over, few enough
     // that most HBM round trips hide behind the previous instance's arithmetic
     StepArgs b = a;
@@ -4110,6 +4120,9 @@ template <typename T>
 static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra, const DevParams<T>& prm, hipStream_t stream) {
     const int ni = run_kernel_block_typed<T>(lpi, a, prm);
     if (!ni || ra.n_steps < 1) return hipErrorInvalidValue;
+    static const int stagger = []() { const char* e = getenv("DVI_ESKF_RUN_STAGGER"); return e ? atoi(e) : 0; }();
+    RunArgs ra_l = ra;
+    ra_l.pad = stagger;
     const size_t lds = (size_t)8 * 2 * 600 * sizeof(T);
     const unsigned blocks = (unsigned)((a.B + ni - 1) / ni);
     static const bool verbose = []() { const char* e = getenv("DVI_ESKF_VERBOSE"); return e && e[0] == '1'; }();
@@ -4118,9 +4131,9 @@ static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra
         said = true;
         fprintf(stderr, "dvi_eskf: runs of pair steps go through eskf_run_kernel (%d instances per block)\n", ni);
     }
-    if (ni == 64) hipLaunchKernelGGL((eskf_run_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm, ra);
-    else if (ni == 32) hipLaunchKernelGGL((eskf_run_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm, ra);
-    else hipLaunchKernelGGL((eskf_run_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm, ra);
+    if (ni == 64) hipLaunchKernelGGL((eskf_run_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
+    else if (ni == 32) hipLaunchKernelGGL((eskf_run_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
+    else hipLaunchKernelGGL((eskf_run_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     return hipGetLastError();
 }
 hipError_t launch_run(int dtype, int lpi, const StepArgs& a, const RunArgs& ra, const HostParams& hp, hipStream_t stream) {
@@ -4144,20 +4157,24 @@ static const int64_t g_epoch_split_max = []() { const char* e = getenv("DVI_ESKF
 template <typename T>
 static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     if (a.B <= 0) return hipSuccess;
-    // a part of the batch: only the kernels that honour sub_first / sub_count (the host asks for it under these conditions only)
-    if (a.sub_count && (a.n_pred < 2 || g_pre_legacy || !a.aux || a.noise || a.K_out || lpi != 1 || (a.sub_count & 63) || (a.sub_first & 63)))
+    // a part of the batch: ONE predicate says when that is possible (the host asks it before it splits a run), and every
+    // branch below that launches a kernel which ignores sub_first / sub_count refuses such a launch on its own as well
+    if (a.sub_count && !epoch_sub_batches_ok(lpi, a.sub_first, a.sub_count, a.n_pred, a.noise != nullptr, a.K_out != nullptr, a.aux != nullptr))
         return hipErrorInvalidValue;
     // 1. lane-per-instance: nominal propagation, Jacobian blocks, residual
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? JB_FULL : JB_CORE) + 9) * sizeof(T);    // + parked measurement
     if (a.n_pred == 1 && !g_pre_legacy) {
+        if (a.sub_count) return hipErrorInvalidValue;      // (eskf_pre4_kernel covers the whole batch)
 #ifdef ESKF_X_PRE4_LDS      // experiment: a larger LDS request = fewer blocks per CU = more, shorter generations
         const size_t stage4 = ESKF_X_PRE4_LDS;
 #else
         const size_t stage4 = (size_t)64 * (prm.jfull ? J_FULL : J_CORE) * sizeof(T);
 #endif
         hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
-    } else if (a.n_pred == 1)
+    } else if (a.n_pred == 1) {
+        if (a.sub_count) return hipErrorInvalidValue;      // (the two-role kernel covers the whole batch)
         hipLaunchKernelGGL((eskf_pre_kernel<T, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
+    }
     else if (a.n_pred >= 2 && !g_pre_legacy && a.aux && (a.B <= g_epoch_split_max || g_epoch_split_max < 0 || a.sub_count)) {
         // epochs: the recurrences, then the Jacobian blocks of all predicts at once.  Pays while the batch under-fills
         // the chip for a lane-per-instance kernel (measured, epoch time against the two-role kernel below, fp64 / fp32,
@@ -4174,7 +4191,9 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
         if ((njobs + 63) / 64 > 0x7fffffffLL) return hipErrorInvalidValue;
         const size_t jl = (size_t)64 * (prm.jfull ? JB_FULL : JB_CORE) * sizeof(T);
         hipLaunchKernelGGL((eskf_jac_kernel<T>), dim3((unsigned)((njobs + 63) / 64)), dim3(128), jl, stream, a, prm);
-    } else if (!a.imu_stride && !a.dt_stride)
+    } else if (a.sub_count)
+        return hipErrorInvalidValue;                       // (the two-role kernel covers the whole batch)
+    else if (!a.imu_stride && !a.dt_stride)
         hipLaunchKernelGGL((eskf_pre_kernel<T, false, true>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
     else
         hipLaunchKernelGGL((eskf_pre_kernel<T, false>), dim3((unsigned)((a.B + 63) / 64)), dim3(128), stage_bytes, stream, a, prm);
@@ -4213,8 +4232,14 @@ static hipError_t launch_flush_typed(const StepArgs& a, const DevParams<T>& prm,
     return hipGetLastError();
 }
 
-// whether launches over a part of the batch are available for epochs (see StepArgs::sub_first)
-bool epoch_sub_batches_available() { return !g_pre_legacy; }
+// Whether an epoch launch over the part [sub_first, sub_first + sub_count) of the batch is possible (see StepArgs::sub_first):
+// the ONE statement of the conditions -- launch_step_typed refuses what it does not allow, dvi_eskf_run_epochs asks it
+// before it puts the halves of a batch on two streams.  n_pred: the launch's predicts (the host passes the shortest
+// epoch of the run).
+bool epoch_sub_batches_ok(int lpi, int64_t sub_first, int64_t sub_count, int n_pred, bool per_instance_noise, bool gain_out, bool have_aux) {
+    return !g_pre_legacy && have_aux && lpi == 1 && !per_instance_noise && !gain_out && n_pred >= 2 && sub_count > 0 &&
+           (sub_count & 63) == 0 && (sub_first & 63) == 0;
+}
 
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
     if (dtype == 0) return launch_flush_typed<double>(a, make_dev_params<double>(hp), stream);

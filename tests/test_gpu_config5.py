@@ -29,7 +29,15 @@ FP64_TOL = 1e-9
 #  hundred steps, where the dynamics amplify a perturbation ~400x per hundred steps -- the fp64-vs-oracle figure there is
 #  1e-12 -- and the worst instance of 8 192 depends on which way single roundings fall: two builds that differ in where
 #  a product is fused into an fma gave 3.3e-3 and 4.3e-2)
-FP32_TOL = {100: (1e-5, 1e-4), 1000: (5e-5, 1e-3), "last100": (1e-1, 1e-4)}
+FP32_TOL = {100: (1e-5, 1e-4), 1000: (5e-5, 1e-3), "last100": (None, 1e-4)}
+# The last hundred steps in x: the WORST of the 8 192 instances is printed, not asserted (it is the dynamics' 400x per
+# hundred steps applied to which way single roundings fell); asserted are the median and the 99th percentile over the
+# instances, and -- the statement about the fp32 kernels themselves -- ONE epoch (33 predicts + the update) forced from
+# the fp64 state at step 9 900, where nothing has been amplified yet.
+# (measured: median 2.9e-6, 99th percentile 6.8e-5, worst 8.8e-3 -- 3.3e-3 and 4.3e-2 in two other builds --; one epoch:
+#  x 5.1e-4 at the worst instance, P 1.7e-6)
+FP32_LAST100_X = {"median": 2e-5, "p99": 5e-4}
+FP32_ONE_EPOCH = (2e-3, 2e-5)
 
 
 def _segments(f, wl, om, acc, dev, checkpoints, first=0, flagged=None):
@@ -97,6 +105,15 @@ def test_config5_ten_thousand_steps_fp64_vs_oracle_and_fp32_vs_fp64():
     s = r64[9900]
     g32.set_state(x=s["x"], P=s["P"], om_old=s["om_old"], acc_old=s["acc_old"], q_old=s["q_old"])
     w32 = _segments(g32, wl, om, acc, dev, (10000,), first=9900, flagged=np.zeros(B, dtype=bool))[10000]
+    # ... and ONE epoch from that state in both precisions (a forced step: nothing amplified)
+    cum_ = np.cumsum(wl.n_pred)
+    e9900 = int(np.searchsorted(cum_, 9900)) + 1
+    cp1 = int(cum_[e9900])
+    h32, h64 = wl.make_filter(dtype=torch.float32, device=dev), wl.make_filter(dtype=torch.float64, device=dev)
+    for h in (h32, h64):
+        h.set_state(x=s["x"], P=s["P"], om_old=s["om_old"], acc_old=s["acc_old"], q_old=s["q_old"])
+    one32 = _segments(h32, wl, om, acc, dev, (cp1,), first=9900, flagged=np.zeros(B, dtype=bool))[cp1]
+    one64 = _segments(h64, wl, om, acc, dev, (cp1,), first=9900)[cp1]
 
     # the oracle on 64 sampled instances: free-running over the full horizon, and restarted at step 9 900
     sample = np.linspace(0, B - 1, 64).astype(np.int64)
@@ -141,7 +158,16 @@ def test_config5_ten_thousand_steps_fp64_vs_oracle_and_fp32_vs_fp64():
     e64, eP64 = _rel(a["x"][sample], ow.x), _relP(a["P"][sample], ow.P)
     e32, eP32 = _rel(w32["x"], a["x"]), _relP(w32["P"], a["P"])
     report.append(f"steps 9900..10000 from the fp64 state at 9900: fp64 vs oracle x {e64:.1e} P {eP64:.1e} | fp32 vs fp64 x {e32:.1e} P {eP32:.1e}")
-    ok &= e64 <= FP64_TOL and eP64 <= 1e2 * FP64_TOL and e32 <= FP32_TOL["last100"][0] and eP32 <= FP32_TOL["last100"][1]
+    ok &= e64 <= FP64_TOL and eP64 <= 1e2 * FP64_TOL and eP32 <= FP32_TOL["last100"][1]
+    per = np.abs(w32["x"] - a["x"]).max(axis=1) / np.maximum(1.0, np.abs(a["x"]).max(axis=1))
+    med, p99 = float(np.median(per)), float(np.percentile(per, 99))
+    e1x, e1P = _rel(one32["x"], one64["x"]), _relP(one32["P"], one64["P"])
+    report.append(f"  the same over the instances: median {med:.1e}, 99th percentile {p99:.1e}, worst {per.max():.1e} (not asserted); "
+                  f"ONE epoch ({cp1 - 9900} predicts + update) from the fp64 state at 9900: fp32 vs fp64 x {e1x:.1e} P {e1P:.1e}")
+    if FP32_LAST100_X["median"] is not None:
+        ok &= med <= FP32_LAST100_X["median"] and p99 <= FP32_LAST100_X["p99"]
+    if FP32_ONE_EPOCH[0] is not None:
+        ok &= e1x <= FP32_ONE_EPOCH[0] and e1P <= FP32_ONE_EPOCH[1]
     print(f"config #5 (B = 8192, 10 000 IMU steps, 300 updates; {clamped.sum()} fp32 instances with a clamped asin):\n  "
           + "\n  ".join(report))
     assert ok, report
