@@ -16,6 +16,9 @@
 #ifdef ESKF_X_STAMPS
 namespace eskf { hipError_t x_read_stamps(unsigned long long* out); hipError_t x_read_cstamps(unsigned long long* out); }
 #endif
+#ifdef ESKF_X_RUNSTAMPS
+namespace eskf { hipError_t x_read_run_stamps(unsigned long long* out); }
+#endif
 
 struct dvi_eskf {
     int64_t B;
@@ -760,6 +763,9 @@ int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, 
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
 
+#ifdef ESKF_X_RUNSTAMPS
+int dvi_eskf_x_run_stamps(unsigned long long* out) { return eskf::x_read_run_stamps(out) == hipSuccess ? 0 : -4; }
+#endif
 #ifdef ESKF_X_STAMPS
 int dvi_eskf_x_stamps(unsigned long long* out) { return eskf::x_read_stamps(out) == hipSuccess ? 0 : -4; }
 int dvi_eskf_x_cstamps(unsigned long long* out) { return eskf::x_read_cstamps(out) == hipSuccess ? 0 : -4; }

@@ -3592,6 +3592,13 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 // Not covered (the launcher falls back to the two kernels): per-instance noise, a gyro block in Q or kept Jacobians
 // (85-word records), gain output, launches over a part of the batch, epochs.
 // ----------------------------------------------------------------------------------
+#if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)     // diagnostic build: 100 MHz stamps of the run kernel's phases
+__device__ unsigned long long g_run_stamps[1024 * 16 * 12];         // [block][step][slot]
+hipError_t x_read_run_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_run_stamps), sizeof(g_run_stamps)); }
+#define ESKF_RSTAMP(SLOT) { if (kstep >= 0 && kstep < 16 && blockIdx.x < 1024 && lane == 0) g_run_stamps[((int)blockIdx.x * 16 + kstep) * 12 + (SLOT)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define ESKF_RSTAMP(SLOT) {}
+#endif
 // One step of a block: phase 1, hand-over, rounds (see above).  kstep: -1 = the launch is this one step (eskf_step_kernel),
 // else the step's number in the run (eskf_run_kernel).
 template <typename T, int ROUNDS>
@@ -3600,6 +3607,7 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
     constexpr int NI = 16 * ROUNDS;
     constexpr int WREGION = 2 * 600;                     // words per wavefront: the images of its two instances
     static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
+    if (wave == 0) ESKF_RSTAMP(0)
     // ---- phase 1
     if (wave < 4) {
         // (the pre phase is what the block's eight wavefronts wait for: its four chains go first on their SIMDs, next to
@@ -3612,6 +3620,7 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         __syncthreads();                                // barrier 1b
         __syncthreads();                                // barrier 2: the staged records are complete
     }
+    if (wave == 0) ESKF_RSTAMP(1)
     // ---- hand-over: the records of this wavefront's instances, three words per lane and round
     T jr[ROUNDS][3];
     {
@@ -3627,6 +3636,7 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         }
     }
     __syncthreads();                                    // everyone has its records: the rows become exchange images
+    if (wave == 0) ESKF_RSTAMP(2)
     // ---- phase 2
     T* smem = reinterpret_cast<T*>(smem_raw) + wave * WREGION;
     const int vb0 = (int)blockIdx.x * (NI / 2) + wave * ROUNDS;
@@ -3644,7 +3654,17 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         //  round instead of being hoisted out of the loop and spilled across it)
         int lane_r = lane;
         asm volatile("" : "+v"(lane_r));
+        // The two wavefronts a block has on a SIMD (w and w + 4) take turns at going first.  Left alone the older one
+        // always wins the issue arbitration: stamps of the run kernel showed wavefront 0 through its four rounds in 21 us,
+        // wavefront 4 in 27, and wavefront 0 waiting 6 us at the end-of-step barrier (same-box A/B: +1.4 % at B = 65 536,
+        // +2.5 % at 8 192).
+        if ((r + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
         cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep);
+        __builtin_amdgcn_s_setprio(0);
+#if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)
+        if (wave == 0) ESKF_RSTAMP(3 + r)
+        if (wave == 4) ESKF_RSTAMP(7 + r)
+#endif
 #pragma unroll
         for (int q = 0; q + 1 < ROUNDS; ++q)
 #pragma unroll
@@ -3701,6 +3721,9 @@ __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams
         // error states and status words of this step are visible to the pre phase of the next (and the images are free
         // to become staging rows again)
         __syncthreads();
+#if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)
+        { const int kstep = k; if (wave == 0) ESKF_RSTAMP(11) }
+#endif
     }
 }
 
