@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- ESKF predict+update pair-steps/s on MI355X (BASELINE.json metric).
 
-One "step" = one fused predict+update launch pair over the rank's batch (B = 65 536 filter
-instances per GPU, fp64, 26-state / 24 error-state), inputs and state resident in HBM.
+One "step" = one predict+update pair of every instance of the rank's batch (B = 65 536 filter
+instances per GPU, fp64, 26-state / 24 error-state), inputs and state resident in HBM; the covariance
+of every instance round-trips memory once per step.  By default a horizon of steps is ONE call of
+dvi_eskf_run_epochs_from = one launch of eskf_run_kernel (the time loop of Filter.run in the kernel);
+`--loop-in-kernel 0` enqueues one dvi_eskf_step call per step instead (two launches per step at this batch).
 Workload: BASELINE config #2/#4 -- the reference's default run (mandala0_mono, default
 config.yaml) on the 1:1 schedule (dt = 1.0), per-instance perturbed initial extrinsic
 DOFs (unfrozen) and per-instance Gaussian noise on IMU and camera measurements.  The
@@ -397,12 +400,16 @@ def main():
         allv = torch.cat(gathered, dim=0) if gathered is not None else dofs
         np.save(args.dump_dofs, allv.cpu().numpy())
 
-    # kernel time of one step from eagerly launched steps (diagnostic; contains the host's launch gaps)
-    n_ev = min(K, 2 * H)
+    # kernel time of one step from eagerly launched steps (diagnostic; contains the host's launch gaps).  With the time
+    # loop in the kernel an eager launch is a whole horizon (every launch of a run is: the profile summaries rely on it).
+    if args.mode == "pair" and LOOP_IN_KERNEL:
+        n_ev, per_ev = 2, H
+    else:
+        n_ev, per_ev = min(K, 2 * H), 1
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
     for k in range(n_ev):
         ev[k][0].record()
-        run.eager(k, 1)
+        run.eager(k * per_ev, per_ev)
         ev[k][1].record()
     torch.cuda.synchronize(dev)
 
@@ -410,7 +417,7 @@ def main():
     st = (run.status_run if (args.mode == "pair" and LOOP_IN_KERNEL) else status).cpu().numpy()
     x_fin = f.x
     ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
-    kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev])) / per_ev
 
     # the same measurement at a batch whose working set does not fit the 256 MiB Infinity Cache (the headline
     # batch's ~225 MB does): what the step sustains when it has to stream from HBM
@@ -454,7 +461,8 @@ def main():
                 # (the PMC pass measured exactly one configuration: the default fp64 pair step at the headline batch through
                 #  the library's default kernels, shared noise model, restore by reading the snapshot -- nothing else gets it)
                 measured_cfg = (B == 65536 and args.lanes == 0 and args.mode == "pair" and not args.per_instance_noise
-                                and not args.restore_copy and not os.environ.get("DVI_ESKF_LIB"))
+                                and not args.restore_copy and not os.environ.get("DVI_ESKF_LIB")
+                                and LOOP_IN_KERNEL == LOOP_IN_KERNEL_DEFAULT and H == 16)
                 traffic = json.load(open(tf)).get("hbm_bytes_per_launch") if measured_cfg else None
             except Exception:
                 traffic = None
@@ -540,7 +548,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_wall": achieved_wall / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "one step = eskf_pre4_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes)",
+                "kernel": ("eskf_run_kernel: ONE launch per horizon (%d steps; the time loop, every step's pre phase and its "
+                           "row-resident covariance rounds inside); achieved = algorithmic bytes of a step / (launch duration / steps "
+                           "of the launch)" % H) if LOOP_IN_KERNEL and not args.lanes else
+                          "one step = eskf_pre4_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes)",
                 "timing": "frac: HIP events on the launch stream around the K steps of the timed region; frac_wall: from "
                           "ms_per_step (host clock, includes the final calibration read, the synchronisation and barriers)",
                 "kernel_ms": kern_ms, "kernel_ms_eager_launches": kern_ms_eager,

@@ -16,7 +16,7 @@ python bench.py > profiles/${tag}_final_bench.json 2> gpurun_out/${tag}_bench.er
 python tools/bench_configs.py 2> gpurun_out/${tag}_configs.err | python -c "
 import sys, json
 print(json.dumps([json.loads(l) for l in sys.stdin if l.startswith('{')], indent=1))" > profiles/${tag}_secondary_configs.json
-bash tools/pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" | grep -E "pre4|cov_rows" > profiles/${tag}_sq_counters.txt
+bash tools/pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES" | grep -E "run_kernel|step_kernel|pre4|cov_rows" > profiles/${tag}_sq_counters.txt
 mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* profiles/traffic_per_launch.json gpurun_out/profiles_${tag}/
 python -c "
 import json

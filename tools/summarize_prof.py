@@ -1,10 +1,18 @@
 """Condenses rocprofv3 CSV output under gpurun_out/ into the small summaries committed
-under profiles/.  usage: summarize_prof.py <tag> <kernel-trace dir> [<fetch pmc dir> <write pmc dir>]"""
+under profiles/.  usage: summarize_prof.py <tag> <kernel-trace dir> [<fetch pmc dir> <write pmc dir>]
+A launch of eskf_run_kernel is a whole horizon of pair steps (bench.py --loop-in-kernel 1: STEPS_PER_RUN_LAUNCH = its
+--horizon, every launch of the profiled command a full horizon): its durations and counters are divided by that to
+give per-step figures, next to the per-launch ones."""
 import collections, csv, glob, json, os, sys
 
 tag, kdir = sys.argv[1], sys.argv[2]
-KEYS = ("eskf_step_kernel", "eskf_pre_kernel", "eskf_pre4_kernel", "eskf_nominal_kernel", "eskf_jac_kernel", "eskf_cov_kernel",
+STEPS_PER_RUN_LAUNCH = int(os.environ.get("STEPS_PER_RUN_LAUNCH", "16"))
+KEYS = ("eskf_run_kernel", "eskf_step_kernel", "eskf_pre_kernel", "eskf_pre4_kernel", "eskf_nominal_kernel", "eskf_jac_kernel", "eskf_cov_kernel",
         "eskf_cov_rows_kernel", "eskf_post_kernel")
+
+
+def steps_of(key):
+    return STEPS_PER_RUN_LAUNCH if key == "eskf_run_kernel" else 1
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
@@ -30,9 +38,11 @@ if trace:
         d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in t]
         info["launches"] = len(d)
         info["avg_ns"] = sum(d) / len(d)
+        info["steps_per_launch"] = steps_of(key)
+        info["avg_ns_per_step"] = info["avg_ns"] / steps_of(key)
         res["step_kernels"][key] = info
     # per step: kernels that do not run every step (the flush) are weighted by their launch count
-    ref = max(v["launches"] for v in res["step_kernels"].values())
+    ref = max(v["launches"] * v["steps_per_launch"] for v in res["step_kernels"].values())
     res["step_avg_ns_sum_of_kernels"] = sum(v["avg_ns"] * v["launches"] / ref for v in res["step_kernels"].values())
 if len(sys.argv) >= 5:
     pm = {}
@@ -56,7 +66,7 @@ if len(sys.argv) >= 5:
         # streaming read (calibrated in the same run on the runtime's copyBuffer of known size);
         # WRITE_SIZE is exact.  Units are KiB.
         def per_step(d):
-            ref = max(v["launches"] for v in d.values())
+            ref = max(v["launches"] * steps_of(k) for k, v in d.items())
             return sum(v["mean_KiB"] * v["launches"] / ref for v in d.values())
         rd = per_step(pm["FETCH_SIZE"]) * 1024 * 2
         wr = per_step(pm["WRITE_SIZE"]) * 1024
