@@ -28,11 +28,12 @@ def run_monte_carlo(batch_total: int, frames: int = 8, seed: int = 4, rank: int 
     start, count = shard_range(batch_total, rank, world)
     wl = monte_carlo_pairs(count, horizon=frames, seed=seed, device=device, first_instance=start)
     f = wl.make_filter()
-    status = torch.zeros(count, dtype=torch.int32, device=device)
+    # the whole run is ONE call: one IMU sample per camera frame, so the time loop of Filter.run runs inside the kernel
+    # (dvi_eskf_run_epochs -> eskf_run_kernel); same bits as a step call per frame
+    status, _ = f.run_epochs(np.ones(frames, dtype=np.int32), wl.dt, wl.om, wl.acc, wl.pos, wl.quat, wl.notch)
     worst = torch.zeros(count, dtype=torch.int32, device=device)
     for k in range(frames):
-        f.step(wl.dt[k], wl.om[k], wl.acc[k], wl.pos[k], wl.quat[k], wl.notch[k], status=status)
-        worst |= status
+        worst |= status[k]
     dofs = gather_calibration(f, group=group)                    # [batch_total, 6] on every rank
     flags = worst.to(torch.float64).reshape(-1, 1)
     from .dist import all_gather_rows

@@ -241,16 +241,21 @@ def test_config4_full_batch_monte_carlo_is_shard_invariant():
     """config #4 at its full size: the calibration estimates of the B = 65 536 noisy Monte-Carlo batch after 6
     pair-steps, computed as one batch, equal what four shards of 16 384 compute for their instances (the shards of a
     multi-GPU run: own noise streams from (seed, global instance), other grid sizes, other wavefront neighbours) --
-    bit for bit."""
+    bit for bit; and the run enqueued as ONE launch (dvi_eskf_run_epochs, the time loop in the kernel) gives the same bits
+    again, at the full size and for a shard."""
     from dvi_ekf_amd.workloads import monte_carlo_pairs
     B, H, S = 65536, 6, 4
     dev = torch.device("cuda", 0)
 
-    def run(n, first):
+    def run(n, first, one_launch=False):
         wl = monte_carlo_pairs(n, horizon=H, seed=4, device=dev, first_instance=first)
         f = wl.make_filter()
-        for k in range(H):
-            st, _ = f.step(wl.dt[k], wl.om[k], wl.acc[k], wl.pos[k], wl.quat[k], wl.notch[k])
+        if one_launch:      # the whole run as ONE launch: the time loop in the kernel (eskf_run_kernel)
+            st, _ = f.run_epochs([1] * H, wl.dt, wl.om, wl.acc, wl.pos, wl.quat, wl.notch)
+            assert int(st.max()) == 0
+        else:
+            for k in range(H):
+                st, _ = f.step(wl.dt[k], wl.om[k], wl.acc[k], wl.pos[k], wl.quat[k], wl.notch[k])
         return f.calibration().clone(), f.x.clone()
 
     dofs, x = run(B, 0)
@@ -259,6 +264,12 @@ def test_config4_full_batch_monte_carlo_is_shard_invariant():
         d_r, x_r = run(B // S, r * (B // S))
         sl = slice(r * (B // S), (r + 1) * (B // S))
         assert torch.equal(d_r, dofs[sl]) and torch.equal(x_r, x[sl]), r
+    # ... and what ONE launch computes for the full batch (64-instance blocks stepping their instances through the run) and
+    # for a shard (32-instance blocks): three launch paths and three block sizes, the same bits
+    d1, x1 = run(B, 0, one_launch=True)
+    assert torch.equal(d1, dofs) and torch.equal(x1, x)
+    d2, x2 = run(B // S, B // S, one_launch=True)
+    assert torch.equal(d2, dofs[B // S:2 * (B // S)]) and torch.equal(x2, x[B // S:2 * (B // S)])
 
 
 def test_random_covariances_row_resident_vs_lds_image_vs_oracle():
