@@ -22,7 +22,7 @@
  *    residual, stale R_WB_old, ...), which are NOT switchable: the reference's saved trajectory pins
  *    every one of them.  The only plumbing switch is dvi_eskf_params.hold_frozen (G1).
  *
- * HIP graphs.  predict / update / step / epoch / step_from / run_epochs / flush / get_* / copy_state only
+ * HIP graphs.  predict / update / step / epoch / step_from / run_epochs / run_epochs_from / flush / get_* / copy_state only
  * enqueue kernels and async copies on `stream` and may be recorded with hipStreamBeginCapture and
  * replayed any number of times: whether an update's error injection is still due is kept on the DEVICE
  * (a bit of the per-instance status word), not in the handle, so a replayed sequence continues from
