@@ -940,6 +940,27 @@ template <typename T>
 struct StepKernArgs { StepArgs a; DevParams<T> prm; };
 template <typename T>
 struct RunKernArgs { StepArgs a; DevParams<T> prm; RunArgs ra; };     // eskf_run_kernel: the same two, then the run
+// Pointers that come out of the kernarg segment through load_kernarg are generic to the compiler (it cannot see that
+// they were kernel arguments): every access through them would be a FLAT instruction -- which counts on the LDS counter
+// as well as on the vector-memory one, so that a wait for an LDS exchange also waits for the covariance stores in
+// flight.  globalise() tells it what they are: device memory.
+template <typename P>
+__device__ __forceinline__ P* globalise(P* p) {
+    // the pointer's bits through an opaque statement, back as a GLOBAL pointer, cast to generic: the address-space
+    // inference then turns every access derived from it into a global one (a global address is the same number in both
+    // address spaces; neither a generic -> global -> generic cast pair nor llvm.assume(!is_shared / !is_private) survived
+    // the optimiser here)
+    typedef P __attribute__((address_space(1))) * gp_t;
+    unsigned long long bits = (unsigned long long)p;
+    asm("" : "+s"(bits));
+    return (P*)(gp_t)bits;
+}
+__device__ __forceinline__ void globalise(StepArgs& a) {
+    a.P = globalise(a.P); a.xs = globalise(a.xs); a.dt = globalise(a.dt); a.om = globalise(a.om); a.acc = globalise(a.acc);
+    a.pos = globalise(a.pos); a.quat = globalise(a.quat); a.notch = globalise(a.notch); a.K_out = globalise(a.K_out);
+    a.status = globalise(a.status); a.J = globalise(a.J); a.aux = globalise(a.aux); a.e = globalise(a.e);
+    a.status_ws = globalise(a.status_ws); a.noise = globalise(a.noise); a.P_src = globalise(a.P_src); a.xs_src = globalise(a.xs_src);
+}
 template <typename S>
 __device__ __forceinline__ S load_kernarg(const char __attribute__((address_space(4))) * p) {
     static_assert(sizeof(S) % 4 == 0, "whole dwords");
@@ -956,6 +977,7 @@ __device__ __forceinline__ void load_run_step_args(int k, StepArgs& a, DevParams
     const char __attribute__((address_space(4))) * ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(ka));
     a = load_kernarg<StepArgs>(ka + offsetof(RunKernArgs<T>, a));
+    globalise(a);
     prm = load_kernarg<DevParams<T>>(ka + offsetof(RunKernArgs<T>, prm));
     const RunArgs ra = load_kernarg<RunArgs>(ka + offsetof(RunKernArgs<T>, ra));
     a.dt = reinterpret_cast<const char*>(a.dt) + (int64_t)k * ra.dt_step;
@@ -976,8 +998,21 @@ __device__ __forceinline__ void load_run_step_args(int k, StepArgs& a, DevParams
 }
 // exchange words of a lane sit in its own staging row, on block words that are only written after barrier 1b
 constexpr int PRE4_XOFF = J_BM;
+// eskf_run_kernel, between two steps of a run: the error state of a step's update and its status word wait for the next
+// step's pre phase in LDS (ES words per instance: e 24 | status word), not in memory -- see step_block.
+constexpr int ES = 25;
+constexpr int E_AREA = 64 * J_CORE;         // first word of the [64][ES] area: right behind the 64 staging rows
+__device__ __forceinline__ double status_as_word(int st, double) { return __longlong_as_double((long long)(unsigned)st); }
+__device__ __forceinline__ float status_as_word(int st, float) { return __int_as_float(st); }
+__device__ __forceinline__ int word_as_status(double w) { return (int)(unsigned)__double_as_longlong(w); }
+__device__ __forceinline__ int word_as_status(float w) { return __float_as_int(w); }
 template <typename T>
-__device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0, int n, T* dst) {
+__device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0, int n, T* dst, const bool e_lds = false, const T* sE_row = nullptr) {
+    if (e_lds) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) dst[i] = sE_row[i0 + i];
+        return;
+    }
 #pragma unroll
 #ifdef ESKF_X_COALESCED_E   // timing experiment only (wrong words): the pending error state read lane-contiguously
     for (int i = 0; i < n; ++i) dst[i] = reinterpret_cast<const T*>(a.e)[(b & ~(int64_t)63) * 24 + (i0 + i) * 64 + (b & 63)];
@@ -988,7 +1023,10 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
 // KEEP (eskf_step_kernel): the block's first NI lanes carry its NI instances and the records STAY in the staging rows --
 // the covariance rounds of the same block take them from there; nothing is written to a.J.
 template <typename T, bool KEEP = false, int NI = 64>
-__device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock) {
+__device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock,
+                                          const bool e_lds = false) {
+    // e_lds (eskf_run_kernel, from the second step of a run on): the error states and status words the block's own rounds
+    // left in LDS for this pre phase ([instance][ES] at word E_AREA); else they are in memory (a.e, a.status_ws)
     // (No re-reading of the arguments from the kernarg segment in here, as the covariance body does: tried for the run
     //  kernel, it changed where the compiler contracts a*b+c in the chains -- one ulp in x after one step -- and with
     //  MachineLICM off for these kernels it is not needed.)
@@ -1010,8 +1048,11 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #endif
     auto X = [&](int w) { return xi[(int64_t)w * B + b]; };
     // deferred injection: device state, see eskf_pre_kernel
+    const T* sE_row = sJ + E_AREA + (NI == 64 || lane < NI ? lane : NI - 1) * ES;
+    const bool e_wanted = e_lds || a.pending_hint;
     int pend_status = 0;
-    if (a.pending_hint) pend_status = a.status_ws[b];
+    if (e_lds) pend_status = word_as_status(sE_row[24]);
+    else if (a.pending_hint) pend_status = a.status_ws[b];
     const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
     const bool inject_now = was_pending && !a.drop_pending && !(pend_status & DVI_STATUS_SINGULAR);
     const T dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? b : 0];
@@ -1036,7 +1077,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #pragma unroll
         for (int i = 0; i < 4; ++i) q[i] = X(6 + i);
         T e9[9], e1215[3], e1821[3];
-        if (a.pending_hint) { load_epend(a, b, 0, 9, e9); load_epend(a, b, 12, 3, e1215); load_epend(a, b, 18, 3, e1821); }
+        if (e_wanted) { load_epend(a, b, 0, 9, e9, e_lds, sE_row); load_epend(a, b, 12, 3, e1215, e_lds, sE_row); load_epend(a, b, 18, 3, e1821, e_lds, sE_row); }
         const int64_t so = a.imu_stride ? b * 3 : 0;
         T om_n[3], acc_n[3];
 #pragma unroll
@@ -1127,7 +1168,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #pragma unroll
         for (int i = 0; i < 4; ++i) qc[i] = X(22 + i);
         T e69[3], e1518[3], e2124[3];
-        if (a.pending_hint) { load_epend(a, b, 6, 3, e69); load_epend(a, b, 15, 3, e1518); load_epend(a, b, 21, 3, e2124); }
+        if (e_wanted) { load_epend(a, b, 6, 3, e69, e_lds, sE_row); load_epend(a, b, 15, 3, e1518, e_lds, sE_row); load_epend(a, b, 21, 3, e2124, e_lds, sE_row); }
         T qraw[4] = {T(0), T(0), T(0), T(1)}, ang_notch = T(0);
         if (a.do_update) {
             const int64_t mo = a.meas_stride ? b : 0;
@@ -1211,7 +1252,8 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
             if (!t_finite(r[0] + r[1] + r[2] + r[3])) flag = T(1);
             if (flag != T(0)) raise_flag();                       // asin argument was clamped, or non-finite residual
         }
-        if (live && was_pending) a.status_ws[b] = pend_status & ~DVI_STATUS_PENDING;  // the injection is done (or dropped)
+        // (with the status word in LDS the one in memory is not touched: the rounds of the run's last step write it anew)
+        if (live && was_pending && !e_lds) a.status_ws[b] = pend_status & ~DVI_STATUS_PENDING;  // the injection is done (or dropped)
         __syncthreads();                                // barrier 2: the 64 staged records are complete
     } else {
         // ---- W2 / W3: Jacobian blocks (Filter.py:249-342), evaluated at the post-predict dofs / notch with the
@@ -1221,7 +1263,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
         for (int i = 0; i < 6; ++i) dofs[i] = X(10 + i);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { notch[i] = X(16 + i); om_o[i] = X(26 + i); }
-        if (a.pending_hint) load_epend(a, b, 9, 9, e918);
+        if (e_wanted) load_epend(a, b, 9, 9, e918, e_lds, sE_row);
         T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
         if (a.noise) {
 #pragma unroll
@@ -2910,7 +2952,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 template <typename T, bool PIN, int LPI, bool SLIM, bool WAVE = false>
 __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevParams<T>& prm_in, T* smem, const int vblock, const int lane,
-                                              const T* jpre = nullptr, const int kstep = -1) {
+                                              const T* jpre = nullptr, const int kstep = -1, const bool e_keep = false, T* e_out = nullptr) {
+    // e_keep / e_out (eskf_run_kernel, every step of a run but the last): the update's error state and status word are handed back
+    // in a register -- lane `row` its component, lane 24 of the instance the status word -- instead of being stored to
+    // a.e / a.status_ws: the block's next pre phase takes them from LDS (step_block)
     StepArgs a = a_in;
     DevParams<T> prm = prm_in;
     // WAVE: the arguments as of now, straight from the kernarg segment (see StepKernArgs); whatever was read before is dead.
@@ -2921,6 +2966,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
             const char __attribute__((address_space(4))) * ka = (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
             a = load_kernarg<StepArgs>(ka + offsetof(StepKernArgs<T>, a));
+            globalise(a);
             prm = load_kernarg<DevParams<T>>(ka + offsetof(StepKernArgs<T>, prm));
             if (kstep >= 0) {
                 const RunArgs ra = load_kernarg<RunArgs>(ka + offsetof(RunKernArgs<T>, ra));
@@ -3403,7 +3449,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         constexpr bool DPPR = LPI == 32;    // the six attitude components of the error state reach every lane as DPP operands
         if (upd && active) {
             if constexpr (!DPPR) sC[row] = e;
-            if (valid) {
+            if (valid && !(WAVE && e_keep)) {
                 if constexpr (LPI == 32) {      // (wave-uniform base + 32-bit lane offset)
                     const int i0_ = vblock * G;
                     char* gE_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.e) + (int64_t)i0_ * 24);
@@ -3478,8 +3524,11 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         }
         gsync();
         if (lig == 0 && valid) {
-            a.status_ws[inst] = status | DVI_STATUS_PENDING;   // the error state of this update awaits injection
+            if (!(WAVE && e_keep)) a.status_ws[inst] = status | DVI_STATUS_PENDING;   // the error state of this update awaits injection
             if (a.status) a.status[inst] = status;
+        }
+        if constexpr (WAVE) {
+            *e_out = (lig == 24) ? status_as_word(valid ? (status | DVI_STATUS_PENDING) : 0, T(0)) : e;
         }
     }
 
@@ -3601,9 +3650,15 @@ hipError_t x_read_run_stamps(unsigned long long* out) { return hipMemcpyFromSymb
 #endif
 // One step of a block: phase 1, hand-over, rounds (see above).  kstep: -1 = the launch is this one step (eskf_step_kernel),
 // else the step's number in the run (eskf_run_kernel).
+// e_from_lds / e_to_lds (eskf_run_kernel): the error states and status words travel from this step's rounds to the
+// next step's pre phase through LDS -- in registers until the block's rounds are over (in the record registers a round
+// has used up), then as [instance][ES] behind the staging rows -- instead of through a.e / a.status_ws (25 MB per step at
+// B = 65 536, read back with a 192-byte stride).  The first step of a run reads them from memory, the last one writes them
+// there: what a run leaves behind is what its steps called one by one leave behind.
 template <typename T, int ROUNDS>
 __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int wave,
-                                           const int lane, const int kstep) {
+                                           const int lane, const int kstep, const bool e_from_lds = false, const bool e_to_lds = false) {
+    static_assert(E_AREA + 64 * ES <= 8 * 2 * 600, "the error-state area fits behind the staging rows");
     constexpr int NI = 16 * ROUNDS;
     constexpr int WREGION = 2 * 600;                     // words per wavefront: the images of its two instances
     static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
@@ -3613,7 +3668,7 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         // (the pre phase is what the block's eight wavefronts wait for: its four chains go first on their SIMDs, next to
         //  the other block's rounds -- same-box A/B of the run kernel: +1 % at B = 65 536, +5.5 % at 8 192)
         __builtin_amdgcn_s_setprio(2);
-        pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x);
+        pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x, e_from_lds);
         __builtin_amdgcn_s_setprio(0);
     } else {
         __syncthreads();                                // barrier 1
@@ -3643,9 +3698,10 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
     const int nB = (int)a.B;
 #pragma unroll 1
     for (int r = 0; r < ROUNDS; ++r) {
+        T e_r = T(0);       // (e_to_lds: what this round hands to the next pre phase)
         // a pair that lies entirely beyond the batch (ragged last block) has nothing to do -- and the body's
         // wave-uniform base + unsigned lane offset addressing needs the pair's first instance to exist
-        if ((vb0 + r) * 2 >= nB) break;
+        if ((vb0 + r) * 2 < nB) {
         // the round's record is always jr[0]: the later ones move up by one afterwards (a handful of register moves per
         // round; indexed by r -- or selected by compares on r, which the compiler turns back into an index -- the array
         // would live in scratch, one scratch round trip per round on the counter the round's loads and stores share)
@@ -3659,8 +3715,9 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         // wavefront 4 in 27, and wavefront 0 waiting 6 us at the end-of-step barrier (same-box A/B: +1.4 % at B = 65 536,
         // +2.5 % at 8 192).
         if ((r + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
-        cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep);
+        cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep, e_to_lds, &e_r);
         __builtin_amdgcn_s_setprio(0);
+        }
 #if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)
         if (wave == 0) ESKF_RSTAMP(3 + r)
         if (wave == 4) ESKF_RSTAMP(7 + r)
@@ -3669,6 +3726,17 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         for (int q = 0; q + 1 < ROUNDS; ++q)
 #pragma unroll
             for (int k = 0; k < 3; ++k) jr[q][k] = jr[q + 1][k];
+        // (the slot the rotation has freed takes the round's error state: after the last round jr[q][0] is round q's)
+        jr[ROUNDS - 1][0] = e_r;
+    }
+    if (e_to_lds) {
+        __syncthreads();                                // every wavefront is through its rounds: the images are dead
+        T* sE = reinterpret_cast<T*>(smem_raw) + E_AREA;
+        const int grp = lane >> 5, lig = lane & 31;
+        if (lig <= 24) {
+#pragma unroll
+            for (int q = 0; q < ROUNDS; ++q) sE[(wave * 2 * ROUNDS + 2 * q + grp) * ES + lig] = jr[q][0];
+        }
     }
 }
 
@@ -3702,7 +3770,8 @@ __device__ __forceinline__ void run_one_step(lds_bytes_t smem_lds, const int wav
     StepArgs a;
     DevParams<T> prm;
     load_run_step_args<T>(k, a, prm);
-    step_block<T, ROUNDS>(a, prm, smem_raw, wave, lane, k);
+    const RunArgs ra = load_kernarg<RunArgs>((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RunKernArgs<T>, ra));
+    step_block<T, ROUNDS>(a, prm, smem_raw, wave, lane, k, k > 0, k + 1 < ra.n_steps);
 }
 template <typename T, int ROUNDS>
 __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams<T> prm0, RunArgs ra0) {
