@@ -3786,7 +3786,11 @@ __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams
     }
 #pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
-        run_one_step<T, ROUNDS>((lds_bytes_t)smem_raw, wave, lane, k);
+        // (the lane index opaque per step: the LDS addresses of the hand-over and of the error-state area are formed again
+        //  every step -- hoisted in front of the time loop they are spilled and come back one scratch load after the other)
+        int lane_k = lane;
+        asm volatile("" : "+v"(lane_k));
+        run_one_step<T, ROUNDS>((lds_bytes_t)smem_raw, wave, lane_k, k);
         // error states and status words of this step are visible to the pre phase of the next (and the images are free
         // to become staging rows again)
         __syncthreads();
