@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
 // the covariance rounds of the same block take them from there; nothing is written to a.J.
 template <typename T, bool KEEP = false, int NI = 64>
 __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock,
-                                          const bool e_lds = false) {
+                                          const bool e_lds = false, const int lane_in = -1, const int role_in = -1) {
     // e_lds (eskf_run_kernel, from the second step of a run on): the error states and status words the block's own rounds
     // left in LDS for this pre phase ([instance][ES] at word E_AREA); else they are in memory (a.e, a.status_ws)
     // (No re-reading of the arguments from the kernarg segment in here, as the covariance body does: tried for the run
@@ -1032,8 +1032,10 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
     //  MachineLICM off for these kernels it is not needed.)
     T* sJ = reinterpret_cast<T*>(smem_raw);
     const int JS = (!KEEP && prm.jfull) ? J_FULL : J_CORE;   // staging rows = whole records: residual words, then the blocks (odd: conflict-free)
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform, and known to be
+    // (the one-launch kernels hand their own lane / wavefront numbers in: inside a time loop the thread index of the
+    //  kernel's entry would have to be kept -- spilled -- across the whole step)
+    const int lane = KEEP && lane_in >= 0 ? lane_in : (int)(threadIdx.x & 63);
+    const int role = KEEP && role_in >= 0 ? role_in : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);     // wave-uniform, and known to be
     const int64_t b0 = (int64_t)vblock * NI;
     const int64_t b_raw = b0 + lane;
     const bool live = (NI == 64 || lane < NI) && b_raw < a.B;
@@ -3668,7 +3670,7 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         // (the pre phase is what the block's eight wavefronts wait for: its four chains go first on their SIMDs, next to
         //  the other block's rounds -- same-box A/B of the run kernel: +1 % at B = 65 536, +5.5 % at 8 192)
         __builtin_amdgcn_s_setprio(2);
-        pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x, e_from_lds);
+        pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x, e_from_lds, lane, wave);
         __builtin_amdgcn_s_setprio(0);
     } else {
         __syncthreads();                                // barrier 1
@@ -3788,8 +3790,12 @@ __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams
     for (int k = 0; k < n_steps; ++k) {
         // (the lane index opaque per step: the LDS addresses of the hand-over and of the error-state area are formed again
         //  every step -- hoisted in front of the time loop they are spilled and come back one scratch load after the other)
-        int lane_k = lane;
-        asm volatile("" : "+v"(lane_k));
+        // ... and the index itself comes from mbcnt (two instructions, no input register) rather than from the thread
+        // index of the kernel's entry, which would be spilled across the step and reloaded -- a scratch round trip in
+        // front of everything -- at the top of every one.
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        const int lane_k = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
         run_one_step<T, ROUNDS>((lds_bytes_t)smem_raw, wave, lane_k, k);
         // error states and status words of this step are visible to the pre phase of the next (and the images are free
         // to become staging rows again)
