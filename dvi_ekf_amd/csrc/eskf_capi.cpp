@@ -17,7 +17,7 @@
 namespace eskf { hipError_t x_read_stamps(unsigned long long* out); hipError_t x_read_cstamps(unsigned long long* out); }
 #endif
 #ifdef ESKF_X_RUNSTAMPS
-namespace eskf { hipError_t x_read_run_stamps(unsigned long long* out); }
+namespace eskf { hipError_t x_read_run_stamps(unsigned long long* out); hipError_t x_read_pre_stamps(unsigned long long* out); }
 #endif
 
 struct dvi_eskf {
@@ -765,6 +765,7 @@ int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, 
 
 #ifdef ESKF_X_RUNSTAMPS
 int dvi_eskf_x_run_stamps(unsigned long long* out) { return eskf::x_read_run_stamps(out) == hipSuccess ? 0 : -4; }
+int dvi_eskf_x_pre_stamps(unsigned long long* out) { return eskf::x_read_pre_stamps(out) == hipSuccess ? 0 : -4; }
 #endif
 #ifdef ESKF_X_STAMPS
 int dvi_eskf_x_stamps(unsigned long long* out) { return eskf::x_read_stamps(out) == hipSuccess ? 0 : -4; }

@@ -926,6 +926,11 @@ hipError_t x_read_cstamps(unsigned long long* out) { return hipMemcpyFromSymbol(
 #define ESKF_STAMP(K) { if (lane == 0 && vblock < 4096) g_x_stamps[(K) * 4096 + vblock] = __builtin_amdgcn_s_memrealtime(); }
 #define ESKF_CSTAMP(K) { if (lane == 0 && (vblock & 7) == 0 && (vblock >> 3) < 4096) g_c_stamps[(K) * 4096 + (vblock >> 3)] = __builtin_amdgcn_s_memrealtime(); }
 hipError_t x_read_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x_stamps), sizeof(g_x_stamps)); }
+#elif defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)   // run-kernel stamps: the pre phase of a block's LAST step, wavefront 0
+__device__ unsigned long long g_pre_stamps[1024 * 8];
+hipError_t x_read_pre_stamps(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pre_stamps), sizeof(g_pre_stamps)); }
+#define ESKF_STAMP(K) { if (lane == 0 && vblock < 1024) g_pre_stamps[vblock * 8 + (K)] = __builtin_amdgcn_s_memrealtime(); }
+#define ESKF_CSTAMP(K) {}
 #else
 #define ESKF_STAMP(K) {}
 #define ESKF_CSTAMP(K) {}
@@ -1090,7 +1095,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #pragma unroll
             for (int i = 0; i < 3; ++i) gpos[i] = gp[i];
         }
-#ifdef ESKF_X_STAMPS
+#if defined(ESKF_X_STAMPS) || defined(ESKF_X_RUNSTAMPS)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         ESKF_STAMP(1)

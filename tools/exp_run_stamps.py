@@ -31,3 +31,12 @@ first = s[s[:, 0, 0] - t0 < 5]
 print("total run of a first-generation block: %.1f us; whole launch %.1f us" % (np.median(first[:, 15, 11] - first[:, 0, 0]), s[:, 15, 11].max() - t0))
 for k in (0, 1, 8):
     print("step %d: pre %.2f, rounds(w0) %s" % (k, np.median(s[:, k, 1] - s[:, k, 0]), ["%.2f" % np.median(s[:, k, 3 + r] - s[:, k, 2 + r]) for r in range(4)]))
+
+# the pre phase of every block's last step from the inside (wavefront 0: position / velocity / attitude chain)
+pb = np.zeros(1024 * 8, dtype=np.uint64)
+L.dvi_eskf_x_pre_stamps.argtypes = [C.c_void_p]
+if L.dvi_eskf_x_pre_stamps(pb.ctypes.data) == 0:
+    q = pb.reshape(1024, 8)[:nb].astype(np.float64) / 100.0
+    m = lambda a, b: np.median(q[:, a] - q[:, b])
+    print("pre phase, wavefront 0, last step (us): loads arrived %.2f | phase A %.2f | barrier 1 %.2f | 1b + phase B + state stores %.2f | barrier 2 %.2f"
+          % (m(1, 0), m(2, 1), m(3, 2), m(4, 3), m(5, 4)))
