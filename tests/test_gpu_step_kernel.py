@@ -43,7 +43,7 @@ def test_one_launch_step_equals_the_two_kernels_bit_for_bit(tmp_path, scenario):
 
 
 @pytest.mark.parametrize("batch,dtype,rounds", [(777, "f64", "1"), (777, "f64", "4"), (1500, "f64", "2"), (515, "f32", "4"),
-                                                (2048, "f64", "")])
+                                                (2048, "f64", ""), (5, "f64", ""), (5, "f32", "4")])
 def test_run_in_one_launch_equals_the_steps_one_by_one(batch, dtype, rounds):
     """dvi_eskf_run_epochs with one predict per epoch is one launch of eskf_run_kernel (the time loop in the kernel):
     bit for bit the step-by-step run, also started from another handle's state, continued, and with shared streams."""
