@@ -14,6 +14,13 @@
 // by the next step's pre kernel or, when the state is read in between, by eskf_post_kernel.  See
 // the "Work split" comment below and DESIGN.md section 4.
 //
+// One launch instead of two or three (round 4): eskf_step_kernel runs the same pre chains and the same covariance body
+// in ONE launch -- a block's pre phase hands the records of its 16 / 32 / 64 instances to its own covariance rounds
+// through LDS staging rows and registers, nothing of them crosses memory --, and eskf_run_kernel puts the time loop of
+// Filter.run (Filter.py:144-168) around that for runs with one IMU sample per camera frame: a whole run is one launch,
+// the error states and status words of an update reach the next step's pre phase through registers and LDS as well.
+// Both compute the bits of the kernels above; the launcher picks by batch size (launch_step / launch_run).
+//
 // HBM layout:
 //   P  [B][300]  symmetric-packed, one contiguous 2.4 KB record per instance: 12 "double rows" r
 //                of 25 words, word c of double row r is P[r][c] for c <= r, else P[23-r][c-r-1]
