@@ -186,3 +186,36 @@ def test_buffers_a_graph_refers_to_are_not_replaced_after_capture():
     a, b = f.get_state(), e.get_state()
     for key in a:
         assert torch.equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("from_snapshot", [False, True])
+def test_captured_run_in_one_launch_replays_like_the_eager_calls(from_snapshot):
+    """dvi_eskf_run_epochs / run_epochs_from with one predict per epoch -- one launch of eskf_run_kernel, the time loop
+    in the kernel -- recorded into a HIP graph: three replays of a 3-epoch run equal nine eager steps (continuing: every
+    replay's first step injects what the last step of the replay before left pending, which is device state); started
+    from a snapshot handle every replay restarts there and equals one eager run."""
+    B = 200
+    dev = torch.device("cuda", 0)
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False, frozen=(0,) * 6)
+    x0 = _perturbed_x0(ri, B)
+    f = _make(cfg, ri, Q, R, sa, so, B, False, x0)
+    E = 3
+    inp = _inputs(ri, B, E, dev)
+    stack = lambda key: torch.stack([a[key] for a in inp]).contiguous()
+    dt, om, acc, pos, quat, notch = (stack(k) for k in ("dt", "om", "acc", "pos", "quat", "notch"))
+    ones = np.ones(E, dtype=np.int32)
+    st = torch.zeros((E, B), dtype=torch.int32, device=dev)
+    snap = f.clone()
+    e = f.clone()
+    g = _capture(lambda: f.run_epochs(ones, dt, om, acc, pos, quat, notch, src=snap if from_snapshot else None, status=st), dev)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    for rep in range(1 if from_snapshot else 3):
+        for i in range(E):
+            a = inp[i]
+            e.step(a["dt"], a["om"], a["acc"], a["pos"], a["quat"], a["notch"])
+    sf, se = f.get_state(), e.get_state()
+    for key in sf:
+        assert torch.equal(sf[key], se[key]), key
+    assert int(st.max()) == 0
