@@ -4152,28 +4152,24 @@ static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEG
 
 #ifdef ESKF_TU_FUSED
 
-// The one-launch step (eskf_step_kernel).  DVI_ESKF_FUSED=0 switches it off, =1 forces it wherever it is able to run
-// (A/B against the two kernels, and the bitwise test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1|2|4 pins
-// the block size.  Default: by batch size, from same-box A/B runs (fp64 pair step of bench.py, pair-steps/s x1e8, two
-// kernels -> one launch with 16 / 32 / 64 instances per block):
-//     B = 1 024  0.89 -> 0.94 / 0.62 / 0.37      4 096  2.69 -> 3.26 / 2.26 / 1.39      8 192  4.05 -> 4.48 / 3.64 / -
-//     16 384  5.65 -> 4.81 / 5.71 / 4.95      32 768  7.03 -> 5.35 / 6.19 / 6.67      65 536  7.25 -> - / 6.44 / 6.90
-//     262 144 (streams from HBM)  6.67-6.81 -> - / - / 6.96
-// fp32 predict-only (config #3), predict-steps/s x1e9: B = 8 192  0.66 -> 0.80; 65 536  1.46 -> 1.38; 262 144  1.43 -> 1.49;
-// 1 048 576  1.23 -> 1.59.
-// A block's pre phase is serial with its covariance rounds, and the blocks of a generation are in it at the same time:
-// that costs more than the record's round trip through memory while a launch is only two generations of blocks (B =
-// 32 768 ... 65 536), and less once a batch under-fills the chip (one generation: latency is what counts) or is many
-// generations long (the blocks drift apart, one block's pre phase runs next to its neighbour's rounds).
+// The one-launch step (eskf_step_kernel).  DVI_ESKF_FUSED=0 switches it off (A/B against the two kernels, and the bitwise
+// test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1|2|4 pins the block size.  Default: by batch size, from
+// same-box A/B runs with the final build (fp64 pair step of bench.py --loop-in-kernel 0, pair-steps/s x1e8, two kernels ->
+// one launch with 16 / 32 / 64 instances per block):
+//     B = 8 192  3.98 -> 4.78 / 4.76 / 3.08     16 384  5.45 -> 5.19 / 6.27 / 5.50     24 576  6.05 -> 5.57 / 6.29 / 6.03
+//     32 768  6.72 -> 5.38 / 6.63 / 7.37     49 152  7.12 -> 5.53 / 6.66 / 7.27     65 536  7.06 -> 5.67 / 6.89 / 7.44
+//     131 072  6.83 -> 5.45 / 6.83 / 7.22
+// (The first complete build of the kernel lost to the two kernels between 32 768 and 65 536 -- a launch there is two
+// generations of blocks that are all in their pre phase at the same time -- and won below and above; what turned the middle
+// around were the code-generation fixes of DESIGN.md section 6, "Round 4": no FLAT accesses, no spilled scalar registers.)
 static const int g_fused = []() { const char* e = getenv("DVI_ESKF_FUSED"); return e ? atoi(e) : -1; }();     // -1: by batch
 static const int g_fused_rounds = []() { const char* e = getenv("DVI_ESKF_FUSED_ROUNDS"); return e ? atoi(e) : 0; }();
 static int step_kernel_rounds(int64_t B) {          // 0: the two kernels
     if (g_fused == 0) return 0;
     if (g_fused_rounds == 1 || g_fused_rounds == 2 || g_fused_rounds == 4) return g_fused_rounds;
     if (B <= 12288) return 1;
-    if (B <= 24576) return 2;
-    if (B >= 131072 || g_fused > 0) return 4;
-    return 0;
+    if (B <= 28672) return 2;
+    return 4;
 }
 // (the kernel asks for 75 KB of LDS per block in fp64: checked once per device against what a block may have)
 static bool device_lds_fits(size_t bytes) {
@@ -4215,7 +4211,7 @@ static int run_kernel_rounds(int64_t B) {
     if (g_run == 0) return 0;
     if (g_run_rounds == 1 || g_run_rounds == 2 || g_run_rounds == 4) return g_run_rounds;
     if (B <= 12288) return 1;
-    if (B <= 24576) return 2;
+    if (B <= 28672) return 2;
     return 4;
 }
 template <typename T>
