@@ -2994,11 +2994,11 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     using namespace rowk;
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
     static_assert(!SLIM || LPI == 32, "SLIM: 32 lanes per instance");
-    static_assert(!WAVE || (SLIM && !PIN), "WAVE: the slim build with the shared noise model");
+    static_assert(!WAVE || SLIM, "WAVE: the slim build");
     constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
     constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
     // (with per-instance noise the 24-word noise record follows the residual: 664 words, 15 wavefronts per CU)
-    constexpr int REGION = WAVE ? 600 : SLIM ? (PIN ? 664 : 640) : PIN ? R_REGION_PIN : R_REGION;
+    constexpr int REGION = WAVE ? (PIN ? 664 : 600) : SLIM ? (PIN ? 664 : 640) : PIN ? R_REGION_PIN : R_REGION;
     constexpr int R_C = SLIM ? 600 : rowk::R_C;
     constexpr int R_RES = SLIM ? 624 : rowk::R_RES;
     constexpr int R_J = SLIM ? 0 : rowk::R_J;      // (SLIM: never addressed)
@@ -3211,6 +3211,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         if constexpr (WAVE) {
 #pragma unroll
             for (int k = 0; k < NJ; ++k) j0[k] = jpre[k];
+            if (PIN) r0.y = reinterpret_cast<const T*>(a.noise)[(int64_t)inst * NOISE_WORDS + (lig < 24 ? lig : 23)];
         } else {
             ESKF_LOAD_J(j0, r0, inst, 0)
         }
@@ -3652,7 +3653,7 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 // (two blocks per CU: while one is in phase 1 the other one's eight wavefronts have the CU).
 // ROUNDS = 4: full batches (NI = 64: every lane of phase 1 busy); 2 / 1: batches that would not fill the chip with
 // 64-instance blocks (phase 1 then runs with 32 / 16 of its 64 lanes, which is free on idle SIMDs).
-// Not covered (the launcher falls back to the two kernels): per-instance noise, a gyro block in Q or kept Jacobians
+// Not covered (the launcher falls back to the two kernels): per-instance noise at more than 12 288 instances, a gyro block in Q or kept Jacobians
 // (85-word records), gain output, launches over a part of the batch, epochs.
 // ----------------------------------------------------------------------------------
 #if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)     // diagnostic build: 100 MHz stamps of the run kernel's phases
@@ -3669,12 +3670,14 @@ hipError_t x_read_run_stamps(unsigned long long* out) { return hipMemcpyFromSymb
 // has used up), then as [instance][ES] behind the staging rows -- instead of through a.e / a.status_ws (25 MB per step at
 // B = 65 536, read back with a 192-byte stride).  The first step of a run reads them from memory, the last one writes them
 // there: what a run leaves behind is what its steps called one by one leave behind.
-template <typename T, int ROUNDS>
+// PIN: per-instance noise (the tuning populations): the images are 664 words per instance (the noise record behind the
+// exchange image), 85 KB of LDS per block in fp64 -- one block per CU, which is all a population needs.
+template <typename T, int ROUNDS, bool PIN = false>
 __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int wave,
                                            const int lane, const int kstep, const bool e_from_lds = false, const bool e_to_lds = false) {
     static_assert(E_AREA + 64 * ES <= 8 * 2 * 600, "the error-state area fits behind the staging rows");
     constexpr int NI = 16 * ROUNDS;
-    constexpr int WREGION = 2 * 600;                     // words per wavefront: the images of its two instances
+    constexpr int WREGION = 2 * (PIN ? 664 : 600);       // words per wavefront: the images of its two instances
     static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
     if (wave == 0) ESKF_RSTAMP(0)
     // ---- phase 1
@@ -3729,7 +3732,7 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         // wavefront 4 in 27, and wavefront 0 waiting 6 us at the end-of-step barrier (same-box A/B: +1.4 % at B = 65 536,
         // +2.5 % at 8 192).
         if ((r + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
-        cov_rows_body<T, false, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep, e_to_lds, &e_r);
+        cov_rows_body<T, PIN, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep, e_to_lds, &e_r);
         __builtin_amdgcn_s_setprio(0);
         }
 #if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)
@@ -3754,14 +3757,14 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
     }
 }
 
-template <typename T, int ROUNDS>
+template <typename T, int ROUNDS, bool PIN = false>
 __global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // (the wavefront's number as a SCALAR: everything derived from it -- the role, the image address, the pair index and
     //  with it the wave-uniform bases of the covariance body's addressing -- stays in scalar registers)
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
-    step_block<T, ROUNDS>(a, prm, smem_raw, wave, lane, -1);
+    step_block<T, ROUNDS, PIN>(a, prm, smem_raw, wave, lane, -1);
 }
 
 // ----------------------------------------------------------------------------------
@@ -3778,16 +3781,16 @@ __global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams
 // front of the time loop and spilled across it.  As a real function call the step costs the callee-saved registers'
 // round trip through scratch: 100 KB per block and step.)
 typedef unsigned char __attribute__((address_space(3))) * lds_bytes_t;
-template <typename T, int ROUNDS>
+template <typename T, int ROUNDS, bool PIN>
 __device__ __forceinline__ void run_one_step(lds_bytes_t smem_lds, const int wave, const int lane, const int k) {
     unsigned char* smem_raw = (unsigned char*)smem_lds;
     StepArgs a;
     DevParams<T> prm;
     load_run_step_args<T>(k, a, prm);
     const RunArgs ra = load_kernarg<RunArgs>((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RunKernArgs<T>, ra));
-    step_block<T, ROUNDS>(a, prm, smem_raw, wave, lane, k, k > 0, k + 1 < ra.n_steps);
+    step_block<T, ROUNDS, PIN>(a, prm, smem_raw, wave, lane, k, k > 0, k + 1 < ra.n_steps);
 }
-template <typename T, int ROUNDS>
+template <typename T, int ROUNDS, bool PIN = false>
 __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams<T> prm0, RunArgs ra0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -3808,7 +3811,7 @@ __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams
         int zero = 0;
         asm volatile("" : "+v"(zero));
         const int lane_k = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)zero));
-        run_one_step<T, ROUNDS>((lds_bytes_t)smem_raw, wave, lane_k, k);
+        run_one_step<T, ROUNDS, PIN>((lds_bytes_t)smem_raw, wave, lane_k, k);
         // error states and status words of this step are visible to the pre phase of the next (and the images are free
         // to become staging rows again)
         __syncthreads();
@@ -4180,14 +4183,15 @@ static bool device_lds_fits(size_t bytes) {
 }
 template <typename T>
 static bool step_kernel_covers(int lpi, const StepArgs& a, const DevParams<T>& prm) {
-    static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 600 * sizeof(double));
-    return lds_ok && step_kernel_rounds(a.B) != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count && !prm.jfull &&
-           !prm.q_gyro && a.B < 0x7fffffffLL;
+    static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 664 * sizeof(double));
+    // (per-instance noise: the 16-instance blocks only -- a population is a small batch, and the 85 KB images are one block per CU)
+    return lds_ok && step_kernel_rounds(a.B) != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.K_out &&
+           (!a.noise || step_kernel_rounds(a.B) == 1) && !a.sub_count && !prm.jfull && !prm.q_gyro && a.B < 0x7fffffffLL;
 }
 template <typename T>
 static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     const int rounds = step_kernel_rounds(a.B);
-    const size_t lds = (size_t)8 * 2 * 600 * sizeof(T);     // 76 800 B (fp64): two blocks per CU
+    const size_t lds = (size_t)8 * 2 * (a.noise ? 664 : 600) * sizeof(T);     // 76 800 B (fp64): two blocks per CU
     const unsigned blocks = (unsigned)((a.B + 16 * rounds - 1) / (16 * rounds));
     // (DVI_ESKF_VERBOSE=1: one line on stderr the first time this path is taken -- the tests of the one-launch step
     //  make sure with it that they are not comparing the two-kernel path with itself)
@@ -4197,7 +4201,8 @@ static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm,
         said = true;
         fprintf(stderr, "dvi_eskf: single-predict launches go through eskf_step_kernel (%d instances per block)\n", 16 * rounds);
     }
-    if (rounds == 4) hipLaunchKernelGGL((eskf_step_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm);
+    if (a.noise) hipLaunchKernelGGL((eskf_step_kernel<T, 1, true>), dim3(blocks), dim3(512), lds, stream, a, prm);
+    else if (rounds == 4) hipLaunchKernelGGL((eskf_step_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm);
     else if (rounds == 2) hipLaunchKernelGGL((eskf_step_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm);
     else hipLaunchKernelGGL((eskf_step_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm);
     return hipGetLastError();
@@ -4216,10 +4221,10 @@ static int run_kernel_rounds(int64_t B) {
 }
 template <typename T>
 static int run_kernel_block_typed(int lpi, const StepArgs& a, const DevParams<T>& prm) {
-    static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 600 * sizeof(double));
+    static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 664 * sizeof(double));
     const int rounds = run_kernel_rounds(a.B);
-    const bool ok = lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count &&
-                    !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
+    const bool ok = lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && (!a.noise || rounds == 1) && !a.K_out &&
+                    !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
     return ok ? 16 * rounds : 0;
 }
 int run_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
@@ -4233,7 +4238,7 @@ static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra
     static const int stagger = []() { const char* e = getenv("DVI_ESKF_RUN_STAGGER"); return e ? atoi(e) : 0; }();
     RunArgs ra_l = ra;
     ra_l.pad = stagger;
-    const size_t lds = (size_t)8 * 2 * 600 * sizeof(T);
+    const size_t lds = (size_t)8 * 2 * (a.noise ? 664 : 600) * sizeof(T);
     const unsigned blocks = (unsigned)((a.B + ni - 1) / ni);
     static const bool verbose = []() { const char* e = getenv("DVI_ESKF_VERBOSE"); return e && e[0] == '1'; }();
     static bool said = false;
@@ -4241,7 +4246,8 @@ static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra
         said = true;
         fprintf(stderr, "dvi_eskf: runs of pair steps go through eskf_run_kernel (%d instances per block)\n", ni);
     }
-    if (ni == 64) hipLaunchKernelGGL((eskf_run_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
+    if (a.noise) hipLaunchKernelGGL((eskf_run_kernel<T, 1, true>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
+    else if (ni == 64) hipLaunchKernelGGL((eskf_run_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     else if (ni == 32) hipLaunchKernelGGL((eskf_run_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     else hipLaunchKernelGGL((eskf_run_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     return hipGetLastError();

@@ -18,6 +18,7 @@ def main(scenario, out):
         "frozen_hold": ((1,) * 6, True, torch.float64, False, 130),
         "keep_jac": ((0,) * 6, False, torch.float64, True, 200),
         "fp32": ((0, 1, 0, 1, 0, 0), False, torch.float32, False, 515),
+        "pin": ((0,) * 6, False, torch.float64, False, 333),      # per-instance noise records (a tuning population)
     }[scenario]
     rng = np.random.default_rng(99)
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=frozen)
@@ -28,6 +29,11 @@ def main(scenario, out):
     f = _make(cfg, ri, Q, Rl, sa, so, B, hold, x0, dtype=dtype)
     if keep:
         f.keep_jacobians(True)
+    if scenario == "pin":
+        q13 = np.tile(np.diag(Q), (B, 1)) * rng.uniform(0.5, 2.0, (B, 13))
+        q13[:, 3:6] = 0.0                                       # (no gyro block in Q: the run-mode model)
+        r7 = np.tile(np.diag(Rl), (B, 1)) * rng.uniform(0.5, 2.0, (B, 7))
+        f.set_noise_per_instance(q13, r7, np.tile(so, (B, 1)) * rng.uniform(0.5, 2.0, (B, 3)))
     f.set_state(x=x0, P=P0, om_old=rng.normal(0, 0.5, (B, 3)), acc_old=rng.normal(0, 20.0, (B, 3)))
     res = {}
     g = f.clone()               # a single predict from the initial state (nothing pending), looked at in isolation

@@ -17,11 +17,16 @@ def same(a, b, what):
         assert np.array_equal(x, y, equal_nan=True), (what, k, float(np.nanmax(np.abs(x - y))))
 
 
-def main(B, dtype):
+def main(B, dtype, pin=False):
     dev = torch.device("cuda", 0)
     H = 6
     wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, dtype=dtype)
     f = wl.make_filter()
+    if pin:     # per-instance noise records (a tuning population): the one-launch kernels with the 664-word images
+        rng = np.random.default_rng(5)
+        q13 = np.tile(np.diag(wl.Q), (B, 1)) * rng.uniform(0.5, 2.0, (B, 13))
+        q13[:, 3:6] = 0.0
+        f.set_noise_per_instance(q13, np.tile(np.diag(wl.R), (B, 1)) * rng.uniform(0.5, 2.0, (B, 7)))
     snap = f.clone()
     # (a NaN camera position in epoch 2 of instance 3: flagged in that epoch's status words, on both paths)
     pos = wl.pos.clone()
@@ -63,4 +68,4 @@ def main(B, dtype):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), torch.float64 if sys.argv[2] == "f64" else torch.float32)
+    main(int(sys.argv[1]), torch.float64 if sys.argv[2].startswith("f64") else torch.float32, pin=sys.argv[2].endswith("pin"))
