@@ -17,6 +17,13 @@ Pinning: ``tests/test_oracle_golden.py`` checks this twin against the reference'
 saved trajectory ``tests/golden/kf_best_mandala0_mono.txt`` (all 300 values to
 the 9-decimal print rounding).
 
+Quirk flags: every place where the v1 source does something other than what
+its own comments / the textbook ESKF say is behind a named flag of ``RefParams.quirks``.  The default
+-- all of them on -- is the v1 source, which is what the saved trajectory pins;
+``tests/test_oracle_quirks.py`` switches them off one at a time and shows that the saved trajectory
+resolves every one of them (the restatement is pinned quirk by quirk, not only as a whole).  The HIP
+kernels and the C restatement implement the default set only.
+
 Conventions: quaternions are stored xyzw (Quaternion.py:113-115); all maths fp64.
 """
 from __future__ import annotations
@@ -31,6 +38,33 @@ NE = 24  # error state     (state.py:91)
 NN = 13  # process noise   (Filter.py:52)
 NM = 7   # measurement     (Filter.py:51)
 SEL = (18, 19, 20, 21, 22, 23, 15)  # rows picked by H (Filter.py:83-85)
+
+# v1 behaviours that a "corrected" filter would not have; name -> where it comes from
+QUIRKS = {
+    "Q1_jac_col_shift": "symbols.py:103,107; Filter.py:279-285 -- camera-row Jacobian blocks land one state block early",
+    "Q2_vtr_is_ptr": "Probe.py:458 -- the 'true' v_CB is the true p_CB",
+    "Q3_dqc_axis_theta": "state.py:124 -- the camera error quaternion turns about the IMU error axis",
+    "Q4_q_imu_zero": "Filter.py:40,68-72,110-117 -- IMU block of Q built with dt = 0 in run mode",
+    "Q5_jac_at_sigma": "Filter.py:330-333 -- Jacobians evaluated at noise = sigma, not 0",
+    "Q6_half_angle_residual": "Quaternion.py:138-147 -- rotation residual asin|v| (half the angle)",
+    "Q7_stale_Rwb_old": "Filter.py:227,254,327 -- Fx after an update uses the pre-update attitude",
+    "Q8_jac_uses_new_dofs": "Filter.py:220-221,325-326 -- Fx uses post-predict dofs / notch with pre-predict omega, a, R",
+    "Q9_Rc_uses_om_old": "equations.py:50,86 -- camera attitude integrated with omega_old, not the mean rate",
+    "Q10_markley_first_order": "equations.py:46; state.py:67; scipy 1.10.1 -- Markley on the non-orthogonal R + R[.]x",
+}
+V1 = frozenset(QUIRKS)
+
+
+def ref_process_noise(dt, sigma_a, sigma_om, rw_var, quirks=V1):
+    """Q of Filter.__init__ / update_noise_matrices (Filter.py:68-72,110-117).  The run-mode filter builds it
+    once with self._dt = 0.0 (Filter.py:40): the IMU block is zero (Q4); without the quirk it is what
+    update_noise_matrices would give with the step in hand."""
+    d = 0.0 if "Q4_q_imu_zero" in quirks else dt
+    Q = np.eye(NN)
+    Q[0:3, 0:3] = d ** 2 * np.asarray(sigma_a, dtype=float) ** 2 * np.eye(3)
+    Q[3:6, 3:6] = d ** 2 * np.asarray(sigma_om, dtype=float) ** 2 * np.eye(3)
+    Q[6:13, 6:13] = np.diag(rw_var)
+    return Q
 
 
 # --------------------------------------------------------------------------- #
@@ -97,8 +131,14 @@ def mat_to_quat_markley(M):
     return q / math.sqrt(q @ q)
 
 
-def quat_from_mat(M):
-    """Quaternion(val=M, do_normalise=True) (Quaternion.py:45-46,69)."""
+def quat_from_mat(M, orthogonalise=False):
+    """Quaternion(val=M, do_normalise=True) (Quaternion.py:45-46,69).  orthogonalise: what newer scipy does with
+    a matrix that is not a rotation (nearest rotation by SVD first) -- the alternative to quirk Q10."""
+    if orthogonalise:
+        U, _, Vt = np.linalg.svd(M)
+        if np.linalg.det(U @ Vt) < 0:
+            U[:, -1] = -U[:, -1]
+        M = U @ Vt
     return quat_nrm(mat_to_quat_markley(M))
 
 
@@ -113,14 +153,14 @@ def quat_about_axis(angle, axis):
     return quat_nrm(np.array([q[1], q[2], q[3], q[0]]))
 
 
-def quat_angle_axis_residual(q):
+def quat_angle_axis_residual(q, half_angle=True):
     """err_q.angle * err_q.axis (Filter.py:371; Quaternion.py:138-167).
-    angle = asin(|v|); axis = v/|v| unless asin(|v|) is exactly 0."""
+    angle = asin(|v|) -- half the rotation angle (Q6) --; axis = v/|v| unless asin(|v|) is exactly 0."""
     nv = math.sqrt(q[0] ** 2 + q[1] ** 2 + q[2] ** 2)
     ang = math.asin(nv)
     if math.isclose(ang, 0):  # default rel_tol 1e-9, abs_tol 0 -> true only for exact 0
         return np.zeros(3)
-    return ang * (q[:3] / nv)
+    return (ang if half_angle else 2.0 * ang) * (q[:3] / nv)
 
 
 # --------------------------------------------------------------------------- #
@@ -188,8 +228,9 @@ class RefParams:
     hold_frozen: bool = False            # G1: False = v1 literal (zero), True = golden-compat (hold)
     sigma_a: np.ndarray = field(default_factory=lambda: np.full(3, 400e-6 * 981 * math.sqrt(10)))
     sigma_om: np.ndarray = field(default_factory=lambda: np.full(3, math.radians(0.005 * math.sqrt(10))))
-    Q: np.ndarray = field(default_factory=lambda: np.eye(NN))   # 13x13 (Filter.py:68-72)
+    Q: np.ndarray = field(default_factory=lambda: np.eye(NN))   # 13x13 (Filter.py:68-72; ref_process_noise)
     R: np.ndarray = field(default_factory=lambda: np.eye(NM))   # 7x7   (Filter.py:75)
+    quirks: frozenset = V1                # SURVEY.md App. A.6; the default is the v1 source
 
 
 class RefFilter:
@@ -225,6 +266,7 @@ class RefFilter:
         """Filter.propagate (Filter.py:219-230)."""
         om = np.asarray(om, dtype=float)
         acc = np.asarray(acc, dtype=float)
+        self._pre_dofs, self._pre_notch = self.x[10:16].copy(), self.x[16:19].copy()
         self._predict_nominal(dt, om, acc)
         self._predict_error(dt)
         self.P = self.Fx @ self.P @ self.Fx.T + self.Fi @ self.prm.Q @ self.Fi.T  # Filter.py:349
@@ -248,7 +290,7 @@ class RefFilter:
         om_avg = (om_o + om_n) / 2                                   # equations.py:44
         R_next = R + R @ skew(dt * om_avg)                           # equations.py:46
         acc_avg = (R @ acc_o + R_next @ acc_n) / 2                   # equations.py:47
-        C_om = R_BC.T @ (om_o + B_om)                                # equations.py:50
+        C_om = R_BC.T @ ((om_o if "Q9_Rc_uses_om_old" in prm.quirks else om_avg) + B_om)   # equations.py:50
         p_next = p + dt * v + (dt ** 2 / 2) * acc_avg                # equations.py:76
         v_next = v + dt * acc_avg                                    # equations.py:77
         notch_next = np.array([notch[0] + dt * notch[1], notch[1] + dt * notch[2], notch[2]])
@@ -259,8 +301,9 @@ class RefFilter:
             for i, fr in enumerate(prm.frozen):
                 if fr:
                     dofs[i] = 0.0
-        q_next = quat_from_mat(R_next)                               # state.py:67
-        qc_next = quat_from_mat(Rc_next)                             # state.py:72
+        svd = "Q10_markley_first_order" not in prm.quirks
+        q_next = quat_from_mat(R_next, svd)                          # state.py:67
+        qc_next = quat_from_mat(Rc_next, svd)                        # state.py:72
         self.x = np.concatenate([p_next, v_next, q_next, dofs, notch_next, pc_next, qc_next])
 
     # reference expressions whose derivatives fill the camera rows -------------
@@ -276,7 +319,10 @@ class RefFilter:
         err_p_C = ev[16:19]
         err_theta_C = ev[19:22]
         n_om = ev[25:28]
-        dofs, notch = self.x[10:16], self.x[16:19]     # post-predict values (Filter.py:325-326)
+        if "Q8_jac_uses_new_dofs" in prm.quirks:
+            dofs, notch = self.x[10:16], self.x[16:19]     # post-predict values (Filter.py:325-326)
+        else:
+            dofs, notch = self._pre_dofs, self._pre_notch
         R_WB = self.R_WB_old                             # Filter.py:327
         om_b = self.om_old                               # Filter.py:328
 
@@ -286,7 +332,7 @@ class RefFilter:
         v = np.zeros(3)
         om = z6 * notch[1]
         p_tr, R_tr, z6_tr = probe_chain(q_est + err_q, prm.L, prm.theta_cam)   # Probe.py:465-468
-        v_tr = p_tr                                      # Probe.py:458 (sic)
+        v_tr = p_tr if "Q2_vtr_is_ptr" in prm.quirks else np.zeros(3)   # Probe.py:458 (sic); v_CB = 0 at any q
         om_probe_tr = z6_tr * notch[1]                   # Probe.py:459 (only q substituted)
 
         R_WB_tr = R_WB @ (np.eye(3) + skew(err_theta))   # symbols.py:129
@@ -318,8 +364,9 @@ class RefFilter:
 
         # evaluation point: error states 0, noise symbols = their std-devs (Filter.py:330-340)
         ev0 = np.zeros(35)
-        ev0[22:25] = prm.sigma_a
-        ev0[25:28] = prm.sigma_om
+        if "Q5_jac_at_sigma" in prm.quirks:
+            ev0[22:25] = prm.sigma_a
+            ev0[25:28] = prm.sigma_om
         # n_dofs / n_notch_acc do not appear in the expressions; any value works
         h = 1e-30
         J = np.empty((6, 35))
@@ -330,7 +377,12 @@ class RefFilter:
 
         # column cursor of Filter.py:279-285 over syms.err_x (symbols.py:107):
         # widths 3,3,3,6,1,3,3 = 22 columns -> state Jacobian lands in cols 0:22
-        Fx[18:24, 0:22] = J[:, 0:22]
+        if "Q1_jac_col_shift" in prm.quirks:
+            Fx[18:24, 0:22] = J[:, 0:22]
+        else:   # the columns where the variables live in the 24-vector: the notch block is 3 wide, not 1
+            Fx[18:24, 0:16] = J[:, 0:16]
+            Fx[18:24, 16:18] = 0.0
+            Fx[18:24, 18:24] = J[:, 16:22]
         # noise: widths 3,3,6,1 = 13 (symbols.py:124)
         Fi = np.zeros((NE, NN))
         Fi[3:15, 0:12] = np.eye(12)
@@ -356,7 +408,7 @@ class RefFilter:
         res_p = np.asarray(pos, dtype=float) - self.x[19:22]
         qm_conj = np.array([-q_meas[0], -q_meas[1], -q_meas[2], q_meas[3]])
         err_q = quat_nrm(quat_mul(qm_conj, self.x[22:26]))                            # Filter.py:370
-        res_q = quat_angle_axis_residual(err_q)
+        res_q = quat_angle_axis_residual(err_q, "Q6_half_angle_residual" in prm.quirks)
         res_n = ang_notch - self.x[16]
         res = np.hstack((res_p, res_q, res_n))
         self.res = res
@@ -369,7 +421,8 @@ class RefFilter:
         # ErrorState.from_array (state.py:105-129) and State.__add__ (46-60)
         theta, theta_c = e[6:9], e[21:24]
         dq = quat_about_axis(math.sqrt(theta @ theta), theta)
-        dqc = quat_about_axis(math.sqrt(theta_c @ theta_c), theta)     # sic: axis = theta (state.py:124)
+        dqc = quat_about_axis(math.sqrt(theta_c @ theta_c),
+                              theta if "Q3_dqc_axis_theta" in prm.quirks else theta_c)   # sic: axis = theta (state.py:124)
         x = self.x.copy()
         x[0:3] += e[0:3]
         x[3:6] += e[3:6]
@@ -387,5 +440,7 @@ class RefFilter:
         G[6:9, 6:9] = np.eye(3) - skew(0.5 * theta)
         G[21:24, 21:24] = np.eye(3) - skew(0.5 * theta_c)
         self.P = G @ P @ G.T                                                           # Filter.py:390
+        if "Q7_stale_Rwb_old" not in prm.quirks:
+            self.R_WB_old = quat_to_mat(self.x[6:10])     # (v1 leaves the pre-update attitude in place until the next predict)
         self.K = K
         return K
