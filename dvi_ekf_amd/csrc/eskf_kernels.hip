@@ -1010,10 +1010,23 @@ __device__ __forceinline__ void load_run_step_args(int k, StepArgs& a, DevParams
 }
 // exchange words of a lane sit in its own staging row, on block words that are only written after barrier 1b
 constexpr int PRE4_XOFF = J_BM;
+// The one-launch kernels (IMG != 0): the staging rows do not lie one behind the other but in the UPPER halves of the
+// block's exchange images (IMG words per instance, sixteen images per block; four rows of 75 words = words 300..599 of an
+// image), so that the lower halves -- the packed covariance of the sixteen instances a block's last round has just
+// worked on -- survive the next step's pre phase (eskf_run_kernel: those covariances never leave the chip between two
+// steps, see step_block).  Row of the block's instance s:
+template <int IMG>
+__device__ __forceinline__ int staging_row_word(int s) {
+    if constexpr (IMG == 0) return s * J_CORE;
+    else return (s >> 2) * IMG + 300 + (s & 3) * J_CORE;
+}
 // eskf_run_kernel, between two steps of a run: the error state of a step's update and its status word wait for the next
-// step's pre phase in LDS (ES words per instance: e 24 | status word), not in memory -- see step_block.
+// step's pre phase in LDS (ES words per instance: e 24 | status word), not in memory -- see step_block.  They lie IN the
+// instance's staging row, on record words that the pre phase only writes after its barrier 1b (Cm[1..17], Dm[0..7]:
+// formed by W2 / W3 from the published trigonometry), while every chain reads its part of the error state before barrier 1.
 constexpr int ES = 25;
-constexpr int E_AREA = 64 * J_CORE;         // first word of the [64][ES] area: right behind the 64 staging rows
+constexpr int E_ROW = J_CM + 1;             // first word of the ES words within the staging row
+static_assert(E_ROW > J_BM + 9 && E_ROW + ES <= J_EM, "error state words: behind the exchange words, on Cm / Dm only");
 __device__ __forceinline__ double status_as_word(int st, double) { return __longlong_as_double((long long)(unsigned)st); }
 __device__ __forceinline__ float status_as_word(int st, float) { return __int_as_float(st); }
 __device__ __forceinline__ int word_as_status(double w) { return (int)(unsigned)__double_as_longlong(w); }
@@ -1034,11 +1047,12 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
 }
 // KEEP (eskf_step_kernel): the block's first NI lanes carry its NI instances and the records STAY in the staging rows --
 // the covariance rounds of the same block take them from there; nothing is written to a.J.
-template <typename T, bool KEEP = false, int NI = 64>
+template <typename T, bool KEEP = false, int NI = 64, int IMG = 0>
 __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int vblock,
                                           const bool e_lds = false, const int lane_in = -1, const int role_in = -1) {
+    static_assert(IMG == 0 || KEEP, "rows inside the exchange images: the one-launch kernels");
     // e_lds (eskf_run_kernel, from the second step of a run on): the error states and status words the block's own rounds
-    // left in LDS for this pre phase ([instance][ES] at word E_AREA); else they are in memory (a.e, a.status_ws)
+    // left in LDS for this pre phase (words E_ROW.. of the instance's staging row); else they are in memory (a.e, a.status_ws)
     // (No re-reading of the arguments from the kernarg segment in here, as the covariance body does: tried for the run
     //  kernel, it changed where the compiler contracts a*b+c in the chains -- one ulp in x after one step -- and with
     //  MachineLICM off for these kernels it is not needed.)
@@ -1062,7 +1076,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
 #endif
     auto X = [&](int w) { return xi[(int64_t)w * B + b]; };
     // deferred injection: device state, see eskf_pre_kernel
-    const T* sE_row = sJ + E_AREA + (NI == 64 || lane < NI ? lane : NI - 1) * ES;
+    const T* sE_row = sJ + staging_row_word<IMG>(NI == 64 || lane < NI ? lane : NI - 1) + E_ROW;
     const bool e_wanted = e_lds || a.pending_hint;
     int pend_status = 0;
     if (e_lds) pend_status = word_as_status(sE_row[24]);
@@ -1070,7 +1084,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
     const bool was_pending = (pend_status & DVI_STATUS_PENDING) != 0;
     const bool inject_now = was_pending && !a.drop_pending && !(pend_status & DVI_STATUS_SINGULAR);
     const T dt = reinterpret_cast<const T*>(a.dt)[a.dt_stride ? b : 0];
-    T* row = sJ + lane * JS;                                   // this lane's staging row
+    T* row = sJ + (IMG ? staging_row_word<IMG>(lane) : lane * JS);     // this lane's staging row
     Jac<T>& J = *reinterpret_cast<Jac<T>*>(row + J_B0);        // its blocks (W2, W3)
     T* xw = row + PRE4_XOFF;                                   // exchange words (trigonometry): on Bm / Cm, which W2 only forms after barrier 1b
     // the non-finite flag of the residual is OR-ed together by W0 (r_p) and W1 (the rest); W2 clears it before barrier 1
@@ -2966,7 +2980,11 @@ __device__ __forceinline__ void wave_sync() {
 }
 template <typename T, bool PIN, int LPI, bool SLIM, bool WAVE = false>
 __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevParams<T>& prm_in, T* smem, const int vblock, const int lane,
-                                              const T* jpre = nullptr, const int kstep = -1, const bool e_keep = false, T* e_out = nullptr) {
+                                              const T* jpre = nullptr, const int kstep = -1, const bool e_keep = false, T* e_out = nullptr,
+                                              const bool p_in_lds = false, const bool p_keep = false) {
+    // p_in_lds / p_keep (eskf_run_kernel): the packed covariance of the wavefront's two instances is already in the lower
+    // halves of their images (words 0..299, where the load phase puts the pieces anyway) -- left there by this wavefront's
+    // last round of the previous step -- / stays there for the first round of the next step instead of being stored
     // e_keep / e_out (eskf_run_kernel, every step of a run but the last): the update's error state and status word are handed back
     // in a register -- lane `row` its component, lane 24 of the instance the status word -- instead of being stored to
     // a.e / a.status_ws: the block's next pre phase takes them from LDS (step_block)
@@ -3198,7 +3216,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         // count (24 + 3 loads -> 5 + 3: +4 % on the step, same box).
         typedef T row_piece_t __attribute__((ext_vector_type(PW)));
         row_piece_t pv_[NV];
-        {
+        if (!(WAVE && p_in_lds)) {
             const int i0_ = vblock * G;
             const char* gPb_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.P_src) + (int64_t)i0_ * 300);
             const unsigned so_ = (unsigned)(inst - i0_) * (unsigned)(300 * sizeof(T));
@@ -3216,10 +3234,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
             ESKF_LOAD_J(j0, r0, inst, 0)
         }
         {
+            if (!(WAVE && p_in_lds)) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int e_ = lig + k * LPI;
-                *reinterpret_cast<row_piece_t*>(sB + PW * (e_ < NPC ? e_ : NPC - 1)) = pv_[k];
+                for (int k = 0; k < NV; ++k) {
+                    const int e_ = lig + k * LPI;
+                    *reinterpret_cast<row_piece_t*>(sB + PW * (e_ < NPC ? e_ : NPC - 1)) = pv_[k];
+                }
             }
             gsync();
             const unsigned rw_ = (unsigned)row;
@@ -3568,7 +3588,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
             if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[j]);
         });
         gsync();
-        if (valid) {
+        if (valid && !(WAVE && p_keep)) {
             // (wave-uniform base + unsigned 32-bit lane offset, the piece's constant in the offset field -- as for the loads)
             const int i0_ = vblock * G;
             char* gPb_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.P) + (int64_t)i0_ * 300);
@@ -3675,17 +3695,23 @@ hipError_t x_read_run_stamps(unsigned long long* out) { return hipMemcpyFromSymb
 template <typename T, int ROUNDS, bool PIN = false>
 __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>& prm, unsigned char* smem_raw, const int wave,
                                            const int lane, const int kstep, const bool e_from_lds = false, const bool e_to_lds = false) {
-    static_assert(E_AREA + 64 * ES <= 8 * 2 * 600, "the error-state area fits behind the staging rows");
     constexpr int NI = 16 * ROUNDS;
-    constexpr int WREGION = 2 * (PIN ? 664 : 600);       // words per wavefront: the images of its two instances
-    static_assert(NI * J_CORE <= 8 * WREGION, "the staging rows fit the block's images");
+    constexpr int IMG = PIN ? 664 : 600;                 // words per exchange image (PIN: the noise record behind it)
+    constexpr int WREGION = 2 * IMG;                     // words per wavefront: the images of its two instances
+    static_assert(300 + 4 * J_CORE <= 600, "four staging rows in the upper half of an image, the packed covariance in the lower");
+    // The order of the rounds alternates from step to step of a run (0 1 2 3, then 3 2 1 0, ...): the pair of instances a
+    // wavefront works on LAST in one step is the pair it works on FIRST in the next, and the packed covariance of that
+    // pair stays where the round's store phase has put it anyway -- words 0..299 of the two images -- instead of going to
+    // memory and coming back (a quarter of the covariance traffic of a 64-instance block, all of it with 16 instances per
+    // block).  The first step of a run loads every covariance, the last one stores every one.
+    const bool rev = kstep > 0 && (kstep & 1);
     if (wave == 0) ESKF_RSTAMP(0)
     // ---- phase 1
     if (wave < 4) {
         // (the pre phase is what the block's eight wavefronts wait for: its four chains go first on their SIMDs, next to
         //  the other block's rounds -- same-box A/B of the run kernel: +1 % at B = 65 536, +5.5 % at 8 192)
         __builtin_amdgcn_s_setprio(2);
-        pre4_body<T, true, NI>(a, prm, smem_raw, (int)blockIdx.x, e_from_lds, lane, wave);
+        pre4_body<T, true, NI, IMG>(a, prm, smem_raw, (int)blockIdx.x, e_from_lds, lane, wave);
         __builtin_amdgcn_s_setprio(0);
     } else {
         __syncthreads();                                // barrier 1
@@ -3700,8 +3726,9 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         const int grp = lane >> 5, lig = lane & 31;
         const int w2 = lig + 64 < J_CORE - 1 ? lig + 64 : J_CORE - 1;     // (the record ends at word 74)
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const T* row = sJ + (wave * 2 * ROUNDS + 2 * r + grp) * J_CORE;
+        for (int r = 0; r < ROUNDS; ++r) {      // (jr[r]: the record of the r-th round in THIS step's order)
+            const int rr = rev ? ROUNDS - 1 - r : r;
+            const T* row = sJ + staging_row_word<IMG>(wave * 2 * ROUNDS + 2 * rr + grp);
             jr[r][0] = row[lig];
             jr[r][1] = row[32 + lig];
             jr[r][2] = row[w2];
@@ -3718,7 +3745,8 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         T e_r = T(0);       // (e_to_lds: what this round hands to the next pre phase)
         // a pair that lies entirely beyond the batch (ragged last block) has nothing to do -- and the body's
         // wave-uniform base + unsigned lane offset addressing needs the pair's first instance to exist
-        if ((vb0 + r) * 2 < nB) {
+        const int rr = rev ? ROUNDS - 1 - r : r;
+        if ((vb0 + rr) * 2 < nB) {
         // the round's record is always jr[0]: the later ones move up by one afterwards (a handful of register moves per
         // round; indexed by r -- or selected by compares on r, which the compiler turns back into an index -- the array
         // would live in scratch, one scratch round trip per round on the counter the round's loads and stores share)
@@ -3732,7 +3760,8 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         // wavefront 4 in 27, and wavefront 0 waiting 6 us at the end-of-step barrier (same-box A/B: +1.4 % at B = 65 536,
         // +2.5 % at 8 192).
         if ((r + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
-        cov_rows_body<T, PIN, 32, true, true>(a, prm, smem, vb0 + r, lane_r, j0, kstep, e_to_lds, &e_r);
+        cov_rows_body<T, PIN, 32, true, true>(a, prm, smem, vb0 + rr, lane_r, j0, kstep, e_to_lds, &e_r,
+                                              /*p_in_lds=*/r == 0 && e_from_lds, /*p_keep=*/r == ROUNDS - 1 && e_to_lds);
         __builtin_amdgcn_s_setprio(0);
         }
 #if defined(ESKF_X_RUNSTAMPS) && defined(ESKF_TU_FUSED)
@@ -3743,16 +3772,21 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
         for (int q = 0; q + 1 < ROUNDS; ++q)
 #pragma unroll
             for (int k = 0; k < 3; ++k) jr[q][k] = jr[q + 1][k];
-        // (the slot the rotation has freed takes the round's error state: after the last round jr[q][0] is round q's)
+        // (the slot the rotation has freed takes the round's error state: after the last round jr[q][0] is that of the
+        //  q-th round in this step's order)
         jr[ROUNDS - 1][0] = e_r;
     }
     if (e_to_lds) {
-        __syncthreads();                                // every wavefront is through its rounds: the images are dead
-        T* sE = reinterpret_cast<T*>(smem_raw) + E_AREA;
+        __syncthreads();                                // every wavefront is through its rounds: the images are dead -- but for
+                                                        // the lower halves of the last round's, which nobody writes from here on
+        T* sJ = reinterpret_cast<T*>(smem_raw);
         const int grp = lane >> 5, lig = lane & 31;
         if (lig <= 24) {
 #pragma unroll
-            for (int q = 0; q < ROUNDS; ++q) sE[(wave * 2 * ROUNDS + 2 * q + grp) * ES + lig] = jr[q][0];
+            for (int q = 0; q < ROUNDS; ++q) {
+                const int qq = rev ? ROUNDS - 1 - q : q;
+                sJ[staging_row_word<IMG>(wave * 2 * ROUNDS + 2 * qq + grp) + E_ROW + lig] = jr[q][0];
+            }
         }
     }
 }
@@ -3774,7 +3808,10 @@ __global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams
 // only synchronisation is the block's own barrier between a step's covariance rounds (error state, status words) and the
 // next step's pre phase, which injects them.  Per step the same code as eskf_step_kernel (same bits as n_steps launches);
 // what the run saves on top is the launch boundary per step, and blocks that drift apart run one block's pre phase next
-// to its neighbour's rounds.  P still round-trips memory every step (64 x 2.4 KB per block do not fit a CU).
+// to its neighbour's rounds -- and the covariances of the sixteen instances a block works on last in a step, which it
+// works on first in the next: they stay in the lower halves of the block's exchange images (step_block).  The other 48 of
+// a 64-instance block still round-trip memory every step (64 x 2.4 KB per block do not fit a CU; with 16 instances per
+// block -- batches up to 8 192 -- no covariance leaves the chip between the first and the last step of a run).
 // ----------------------------------------------------------------------------------
 // One step of the run.  (Inlined into the time loop -- which is only affordable because this translation unit is
 // compiled without MachineLICM, see "host-side launchers": with the pass everything the step materialises is hoisted in
@@ -3794,7 +3831,7 @@ template <typename T, int ROUNDS, bool PIN = false>
 __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams<T> prm0, RunArgs ra0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int lane = (int)threadIdx.x & 63;
+    [[maybe_unused]] const int lane = (int)threadIdx.x & 63;      // (the stamps of the diagnostic build)
     const int n_steps = ra0.n_steps;
     // (experiment, DVI_ESKF_RUN_STAGGER=<us>: every other group of 256 blocks starts late, so that the two blocks of a CU
     //  are not in their pre phases at the same time)
@@ -4212,10 +4249,14 @@ static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm,
 // pins it (DVI_ESKF_RUN=0: runs are enqueued step by step)
 static const int g_run = []() { const char* e = getenv("DVI_ESKF_RUN"); return e ? atoi(e) : -1; }();
 static const int g_run_rounds = []() { const char* e = getenv("DVI_ESKF_RUN_ROUNDS"); return e ? atoi(e) : 0; }();
+// (same-box sweep with the covariance of a block's last round resident between the steps, tools/sweep_run_rounds.sh, fp64 pair
+//  steps x1e8 with 16 / 32 / 64 instances per block: B = 4 096 4.64 / 3.00 / 1.80; 8 192 6.96 / 5.82 / 3.54; 12 288 5.57 / 6.37 /
+//  5.21; 16 384 7.18 / 8.37 / 6.88; 24 576 7.25 / 7.87 / 7.16; 32 768 7.21 / 8.43 / 8.85; 49 152 6.98 / 8.36 / 8.45; 65 536 6.99 /
+//  8.33 / 8.73; 131 072 7.00 / 8.40 / 8.75 -- 16-instance blocks while they are one generation, 512 blocks)
 static int run_kernel_rounds(int64_t B) {
     if (g_run == 0) return 0;
     if (g_run_rounds == 1 || g_run_rounds == 2 || g_run_rounds == 4) return g_run_rounds;
-    if (B <= 12288) return 1;
+    if (B <= 8192) return 1;
     if (B <= 28672) return 2;
     return 4;
 }
