@@ -2,10 +2,13 @@
 """bench.py -- ESKF predict+update pair-steps/s on MI355X (BASELINE.json metric).
 
 One "step" = one predict+update pair of every instance of the rank's batch (B = 65 536 filter
-instances per GPU, fp64, 26-state / 24 error-state), inputs and state resident in HBM; the covariance
-of every instance round-trips memory once per step.  By default a horizon of steps is ONE call of
-dvi_eskf_run_epochs_from = one launch of eskf_run_kernel (the time loop of Filter.run in the kernel);
-`--loop-in-kernel 0` enqueues one dvi_eskf_step call per step instead (two launches per step at this batch).
+instances per GPU, fp64, 26-state / 24 error-state), inputs and state resident in HBM.  By default a
+horizon of steps is ONE call of dvi_eskf_run_epochs_from = one launch of eskf_run_kernel (the time loop of
+Filter.run in the kernel): a block steps its own 64 instances, and the covariances of the sixteen it works on
+last in a step -- first in the next -- stay in LDS in between; those of the other 48 round-trip memory every
+step (so the measured traffic of a step, `roofline.traffic`, is BELOW the algorithmic bytes `roofline.achieved`
+is computed from: a quarter of the covariance traffic is not there).  `--loop-in-kernel 0` enqueues one
+dvi_eskf_step call per step instead (one launch per step; every covariance round-trips memory once per step).
 Workload: BASELINE config #2/#4 -- the reference's default run (mandala0_mono, default
 config.yaml) on the 1:1 schedule (dt = 1.0), per-instance perturbed initial extrinsic
 DOFs (unfrozen) and per-instance Gaussian noise on IMU and camera measurements.  The
@@ -548,8 +551,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "frac_wall": achieved_wall / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_over_algorithmic": (traffic / (BYTES_PER_PAIR_F64 * B)) if traffic else None,
                 "kernel": ("eskf_run_kernel: ONE launch per horizon (%d steps; the time loop, every step's pre phase and its "
-                           "row-resident covariance rounds inside); achieved = algorithmic bytes of a step / (launch duration / steps "
+                           "row-resident covariance rounds inside; between two steps of a launch the covariances of a quarter of "
+                           "the instances stay in LDS); achieved = algorithmic bytes of a step / (launch duration / steps "
                            "of the launch)" % H) if LOOP_IN_KERNEL and not args.lanes else
                           "one step = eskf_pre4_kernel + eskf_cov_rows_kernel (dominant; eskf_cov_kernel<LPI> with --lanes)",
                 "timing": "frac: HIP events on the launch stream around the K steps of the timed region; frac_wall: from "
