@@ -198,7 +198,9 @@ int dvi_eskf_run_epochs(dvi_eskf* h, const dvi_eskf_schedule* sched, void* strea
  * saved trajectory, kf_best_mandala0_mono.txt, and of the Monte-Carlo batches), no log rows, shared noise model, default
  * covariance kernel, is ONE launch: the time loop of Filter.run (Filter.py:144-168) runs inside the kernel
  * (eskf_run_kernel), every thread block stepping its own instances from frame to frame; results are bit for bit those of
- * the epoch-by-epoch calls.  Capturable like any other call. */
+ * the epoch-by-epoch calls.  Capturable like any other call.  Within such a run the covariances of a quarter of the
+ * instances (half / all of them for batches up to 28 672 / 8 192) stay in on-chip memory from one frame to the next; what
+ * the handle holds in device memory is complete again when the launch has finished -- as after any other call. */
 
 /* dvi_eskf_run_epochs whose first epoch starts from the (flushed) state of `src`, as dvi_eskf_step_from does for one
  * step: h == copy_state(src) followed by run_epochs, bit for bit, without the copy.  src != NULL; same batch, dtype
