@@ -3671,8 +3671,9 @@ __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void e
 // 2 x 40 MB of the 477 MB a step moves; builds of the two kernels with the record stores / loads compiled out put the
 // bound at 71.6 us against 87.0) and a kernel boundary.  What it costs: the block's phase 1 is serial with its rounds
 // (two blocks per CU: while one is in phase 1 the other one's eight wavefronts have the CU).
-// ROUNDS = 4: full batches (NI = 64: every lane of phase 1 busy); 2 / 1: batches that would not fill the chip with
-// 64-instance blocks (phase 1 then runs with 32 / 16 of its 64 lanes, which is free on idle SIMDs).
+// ROUNDS = 4: full batches (NI = 64: every lane of phase 1 busy); 3 / 2 / 1: batches whose 64-instance blocks would not come
+// out as whole layers of one block per CU (phase 1 then runs with 48 / 32 / 16 of its 64 lanes) -- the launcher decides
+// (pick_rounds).
 // Not covered (the launcher falls back to the two kernels): per-instance noise at more than 12 288 instances, a gyro block in Q or kept Jacobians
 // (85-word records), gain output, launches over a part of the batch, epochs.
 // ----------------------------------------------------------------------------------
@@ -4193,23 +4194,42 @@ static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEG
 #ifdef ESKF_TU_FUSED
 
 // The one-launch step (eskf_step_kernel).  DVI_ESKF_FUSED=0 switches it off (A/B against the two kernels, and the bitwise
-// test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1|2|4 pins the block size.  Default: by batch size, from
-// same-box A/B runs with the final build (fp64 pair step of bench.py --loop-in-kernel 0, pair-steps/s x1e8, two kernels ->
-// one launch with 16 / 32 / 64 instances per block):
-//     B = 8 192  3.98 -> 4.78 / 4.76 / 3.08     16 384  5.45 -> 5.19 / 6.27 / 5.50     24 576  6.05 -> 5.57 / 6.29 / 6.03
-//     32 768  6.72 -> 5.38 / 6.63 / 7.37     49 152  7.12 -> 5.53 / 6.66 / 7.27     65 536  7.06 -> 5.67 / 6.89 / 7.44
-//     131 072  6.83 -> 5.45 / 6.83 / 7.22
+// test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1..4 pins the block size (16 R instances).  Default: the
+// block size whose LAYERS of blocks cost least (pick_rounds).  A CU holds two blocks; a launch of n x 256 blocks is n
+// layers of one block per CU, which a CU works off in pairs.  T2[R] = what a pair of co-resident blocks takes for one
+// step, T1[R] = what a block takes that has its CU to itself (us; tools/sweep_run_rounds.sh at the batches that are
+// exactly one and two layers; only the ratios matter) -- with these eight numbers the model picks the measured best of
+// R = 1..4 at 26 of the 28 points of that sweep (B = 4 096 ... 131 072, both kernels) and is within 1 % of it at the other
+// two.  What it captures is the quantisation: 48-instance blocks at B = 24 576 are exactly two layers (8.2e8 pair-steps/s
+// in a run against 7.7 / 7.1 for 32 / 64), at 32 768 they are 2.7 (7.5 against 8.2 for 64).
 // (The first complete build of the kernel lost to the two kernels between 32 768 and 65 536 -- a launch there is two
 // generations of blocks that are all in their pre phase at the same time -- and won below and above; what turned the middle
 // around were the code-generation fixes of DESIGN.md section 6, "Round 4": no FLAT accesses, no spilled scalar registers.)
+static int pick_rounds(int64_t B, const float (&T1)[4], const float (&T2)[4]) {
+    static const int n_cu = []() {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    int best = 4;
+    double best_t = 0;
+    for (int R = 4; R >= 1; --R) {          // (ties go to the larger block)
+        const int64_t blocks = (B + 16 * R - 1) / (16 * R);
+        const int64_t full = blocks / n_cu, rem = blocks - full * n_cu;
+        double t = (double)(full / 2) * T2[R - 1] + (double)(full % 2) * T1[R - 1];
+        if (rem) t += (full % 2) ? T2[R - 1] - T1[R - 1] : T1[R - 1];      // (a partial layer pairs up with an unpaired full one)
+        if (R == 4 || t < best_t * 0.99) { best = R; best_t = t; }
+    }
+    return best;
+}
 static const int g_fused = []() { const char* e = getenv("DVI_ESKF_FUSED"); return e ? atoi(e) : -1; }();     // -1: by batch
 static const int g_fused_rounds = []() { const char* e = getenv("DVI_ESKF_FUSED_ROUNDS"); return e ? atoi(e) : 0; }();
-static int step_kernel_rounds(int64_t B) {          // 0: the two kernels
+static int step_kernel_rounds(int64_t B, bool pin) {          // 0: the two kernels
     if (g_fused == 0) return 0;
-    if (g_fused_rounds == 1 || g_fused_rounds == 2 || g_fused_rounds == 4) return g_fused_rounds;
-    if (B <= 12288) return 1;
-    if (B <= 28672) return 2;
-    return 4;
+    if (g_fused_rounds >= 1 && g_fused_rounds <= 4) return g_fused_rounds;
+    if (pin && B <= 12288) return 1;        // (per-instance noise records: the 16-instance blocks only)
+    static const float T1[4] = {12.0f, 17.4f, 24.1f, 29.9f}, T2[4] = {17.5f, 26.9f, 36.5f, 46.6f};
+    return pick_rounds(B, T1, T2);
 }
 // (the kernel asks for 75 KB of LDS per block in fp64: checked once per device against what a block may have)
 static bool device_lds_fits(size_t bytes) {
@@ -4222,12 +4242,13 @@ template <typename T>
 static bool step_kernel_covers(int lpi, const StepArgs& a, const DevParams<T>& prm) {
     static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 664 * sizeof(double));
     // (per-instance noise: the 16-instance blocks only -- a population is a small batch, and the 85 KB images are one block per CU)
-    return lds_ok && step_kernel_rounds(a.B) != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.K_out &&
-           (!a.noise || step_kernel_rounds(a.B) == 1) && !a.sub_count && !prm.jfull && !prm.q_gyro && a.B < 0x7fffffffLL;
+    const int rounds = step_kernel_rounds(a.B, a.noise != nullptr);
+    return lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.K_out &&
+           (!a.noise || rounds == 1) && !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
 }
 template <typename T>
 static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
-    const int rounds = step_kernel_rounds(a.B);
+    const int rounds = step_kernel_rounds(a.B, a.noise != nullptr);
     const size_t lds = (size_t)8 * 2 * (a.noise ? 664 : 600) * sizeof(T);     // 76 800 B (fp64): two blocks per CU
     const unsigned blocks = (unsigned)((a.B + 16 * rounds - 1) / (16 * rounds));
     // (DVI_ESKF_VERBOSE=1: one line on stderr the first time this path is taken -- the tests of the one-launch step
@@ -4240,6 +4261,7 @@ static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm,
     }
     if (a.noise) hipLaunchKernelGGL((eskf_step_kernel<T, 1, true>), dim3(blocks), dim3(512), lds, stream, a, prm);
     else if (rounds == 4) hipLaunchKernelGGL((eskf_step_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm);
+    else if (rounds == 3) hipLaunchKernelGGL((eskf_step_kernel<T, 3>), dim3(blocks), dim3(512), lds, stream, a, prm);
     else if (rounds == 2) hipLaunchKernelGGL((eskf_step_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm);
     else hipLaunchKernelGGL((eskf_step_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm);
     return hipGetLastError();
@@ -4249,21 +4271,20 @@ static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm,
 // pins it (DVI_ESKF_RUN=0: runs are enqueued step by step)
 static const int g_run = []() { const char* e = getenv("DVI_ESKF_RUN"); return e ? atoi(e) : -1; }();
 static const int g_run_rounds = []() { const char* e = getenv("DVI_ESKF_RUN_ROUNDS"); return e ? atoi(e) : 0; }();
-// (same-box sweep with the covariance of a block's last round resident between the steps, tools/sweep_run_rounds.sh, fp64 pair
-//  steps x1e8 with 16 / 32 / 64 instances per block: B = 4 096 4.64 / 3.00 / 1.80; 8 192 6.96 / 5.82 / 3.54; 12 288 5.57 / 6.37 /
-//  5.21; 16 384 7.18 / 8.37 / 6.88; 24 576 7.25 / 7.87 / 7.16; 32 768 7.21 / 8.43 / 8.85; 49 152 6.98 / 8.36 / 8.45; 65 536 6.99 /
-//  8.33 / 8.73; 131 072 7.00 / 8.40 / 8.75 -- 16-instance blocks while they are one generation, 512 blocks)
-static int run_kernel_rounds(int64_t B) {
+// (the layer model of pick_rounds with the run kernel's own figures: a quarter / a third / half / all of the covariances
+//  resident between the steps with 64 / 48 / 32 / 16 instances per block -- sixteen-instance blocks are taken while they are one
+//  generation, B <= 8 192: 6.9e8 pair-steps/s, and stop at 7.0e8 however large the batch, a pre phase per round)
+static int run_kernel_rounds(int64_t B, bool pin) {
     if (g_run == 0) return 0;
-    if (g_run_rounds == 1 || g_run_rounds == 2 || g_run_rounds == 4) return g_run_rounds;
-    if (B <= 8192) return 1;
-    if (B <= 28672) return 2;
-    return 4;
+    if (g_run_rounds >= 1 && g_run_rounds <= 4) return g_run_rounds;
+    if (pin && B <= 8192) return 1;
+    static const float T1[4] = {8.9f, 14.1f, 19.3f, 24.0f}, T2[4] = {11.8f, 20.5f, 30.1f, 40.1f};
+    return pick_rounds(B, T1, T2);
 }
 template <typename T>
 static int run_kernel_block_typed(int lpi, const StepArgs& a, const DevParams<T>& prm) {
     static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 664 * sizeof(double));
-    const int rounds = run_kernel_rounds(a.B);
+    const int rounds = run_kernel_rounds(a.B, a.noise != nullptr);
     const bool ok = lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && (!a.noise || rounds == 1) && !a.K_out &&
                     !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
     return ok ? 16 * rounds : 0;
@@ -4289,6 +4310,7 @@ static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra
     }
     if (a.noise) hipLaunchKernelGGL((eskf_run_kernel<T, 1, true>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     else if (ni == 64) hipLaunchKernelGGL((eskf_run_kernel<T, 4>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
+    else if (ni == 48) hipLaunchKernelGGL((eskf_run_kernel<T, 3>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     else if (ni == 32) hipLaunchKernelGGL((eskf_run_kernel<T, 2>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     else hipLaunchKernelGGL((eskf_run_kernel<T, 1>), dim3(blocks), dim3(512), lds, stream, a, prm, ra_l);
     return hipGetLastError();
@@ -4299,7 +4321,7 @@ hipError_t launch_run(int dtype, int lpi, const StepArgs& a, const RunArgs& ra, 
 }
 int step_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
     const bool ok = dtype == 0 ? step_kernel_covers(lpi, a, make_dev_params<double>(hp)) : step_kernel_covers(lpi, a, make_dev_params<float>(hp));
-    return ok ? 16 * step_kernel_rounds(a.B) : 0;
+    return ok ? 16 * step_kernel_rounds(a.B, a.noise != nullptr) : 0;
 }
 hipError_t launch_step_fused(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream) {
     if (dtype == 0) return launch_step_kernel<double>(a, make_dev_params<double>(hp), stream);

@@ -3,7 +3,7 @@ covariance rounds on chip) against the two kernels it replaces, eskf_pre4_kernel
 run the SAME device functions (pre4_body, cov_rows_body) on the same inputs in the same order; only the way the 75-word
 record travels differs (LDS staging rows -> registers instead of memory).  The results must therefore be the same bits:
 state, covariance, status words, through pending injections, zeroed frozen DOFs, non-finite measurements, ragged
-batches, fp32, and for every block size of the one-launch kernel (16 / 32 / 64 instances per block).  The path is
+batches, fp32, and for every block size of the one-launch kernel (16 / 32 / 48 / 64 instances per block).  The path is
 selected per process (DVI_ESKF_FUSED, DVI_ESKF_FUSED_ROUNDS), so each side runs in a child (tests/_pre4_child.py)."""
 import os
 import subprocess
@@ -35,7 +35,7 @@ def _run(tmp_path, scenario, tag, **env_over):
 def test_one_launch_step_equals_the_two_kernels_bit_for_bit(tmp_path, scenario):
     ref = _run(tmp_path, scenario, "split", DVI_ESKF_FUSED="0")
     # (per-instance noise records -- "pin" -- are served by the 16-instance blocks only)
-    for rounds in (("1",) if scenario == "pin" else ("4", "2", "1")):
+    for rounds in (("1",) if scenario == "pin" else ("4", "3", "2", "1")):
         got = _run(tmp_path, scenario, "fused" + rounds, DVI_ESKF_FUSED="1", DVI_ESKF_FUSED_ROUNDS=rounds)
         assert set(ref.files) == set(got.files)
         bad = [k for k in ref.files if not np.array_equal(ref[k], got[k], equal_nan=True)]
@@ -43,7 +43,7 @@ def test_one_launch_step_equals_the_two_kernels_bit_for_bit(tmp_path, scenario):
     assert (ref["st1"][[5, 7, 9]] & 2).all()        # the non-finite measurements were flagged (on both sides)
 
 
-@pytest.mark.parametrize("batch,dtype,rounds", [(777, "f64", "1"), (777, "f64", "4"), (1500, "f64", "2"), (515, "f32", "4"),
+@pytest.mark.parametrize("batch,dtype,rounds", [(777, "f64", "1"), (777, "f64", "4"), (1500, "f64", "2"), (1000, "f64", "3"), (515, "f32", "4"),
                                                 (2048, "f64", ""), (5, "f64", ""), (5, "f32", "4"), (300, "f64pin", "")])
 def test_run_in_one_launch_equals_the_steps_one_by_one(batch, dtype, rounds):
     """dvi_eskf_run_epochs with one predict per epoch is one launch of eskf_run_kernel (the time loop in the kernel):
