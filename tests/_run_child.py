@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_step_kernel.py: a run of pair steps enqueued as ONE launch (dvi_eskf_run_epochs with
 one predict per epoch -> eskf_run_kernel, the time loop in the kernel) against the same steps enqueued one by one, in the
 same process: state, covariance and every epoch's status words must be the same bits.  The block size of the run kernel
-comes from the environment (DVI_ESKF_RUN_ROUNDS), hence the child.  usage: _run_child.py <batch> <f64|f32> <repo root>"""
+comes from the environment (DVI_ESKF_RUN_ROUNDS), hence the child.  usage: _run_child.py <batch> <f64|f32> <repo root> [steps]"""
 import sys
 
 import numpy as np
@@ -17,9 +17,8 @@ def same(a, b, what):
         assert np.array_equal(x, y, equal_nan=True), (what, k, float(np.nanmax(np.abs(x - y))))
 
 
-def main(B, dtype, pin=False):
+def main(B, dtype, pin=False, H=6):
     dev = torch.device("cuda", 0)
-    H = 6
     wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, dtype=dtype)
     f = wl.make_filter()
     if pin:     # per-instance noise records (a tuning population): the one-launch kernels with the 664-word images
@@ -54,8 +53,10 @@ def main(B, dtype, pin=False):
     same(h2.get_state(), ref, "run_epochs_from")
     # D: continuing a run: the second half enqueued on its own must pick up the injection the first half left pending
     g2 = snap.clone()
+    # (three steps, then the rest: an odd and -- with H = 6 -- another odd number of steps, i.e. runs that end on either
+    #  order of the rounds; what stays in LDS between the steps of a run is all in memory when the launch has finished)
     g2.run_epochs([1] * 3, wl.dt[:3], wl.om[:3], wl.acc[:3], pos[:3], wl.quat[:3], wl.notch[:3])
-    g2.run_epochs([1] * 3, wl.dt[3:], wl.om[3:], wl.acc[3:], pos[3:], wl.quat[3:], wl.notch[3:])
+    g2.run_epochs([1] * (H - 3), wl.dt[3:], wl.om[3:], wl.acc[3:], pos[3:], wl.quat[3:], wl.notch[3:])
     same(g2.get_state(), ref, "two halves")
     # E: one input stream shared by the batch (instance 1's), against steps with the broadcast samples
     f3, g3 = snap.clone(), snap.clone()
@@ -68,4 +69,5 @@ def main(B, dtype, pin=False):
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]), torch.float64 if sys.argv[2].startswith("f64") else torch.float32, pin=sys.argv[2].endswith("pin"))
+    main(int(sys.argv[1]), torch.float64 if sys.argv[2].startswith("f64") else torch.float32, pin=sys.argv[2].endswith("pin"),
+         H=int(sys.argv[4]) if len(sys.argv) > 4 else 6)

@@ -45,16 +45,24 @@ def test_one_launch_step_equals_the_two_kernels_bit_for_bit(tmp_path, scenario):
 
 @pytest.mark.parametrize("batch,dtype,rounds", [(777, "f64", "1"), (777, "f64", "4"), (1500, "f64", "2"), (1000, "f64", "3"), (515, "f32", "4"),
                                                 (2048, "f64", ""), (5, "f64", ""), (5, "f32", "4"), (300, "f64pin", "")])
-def test_run_in_one_launch_equals_the_steps_one_by_one(batch, dtype, rounds):
+def test_run_in_one_launch_equals_the_steps_one_by_one(batch, dtype, rounds, steps=6):
     """dvi_eskf_run_epochs with one predict per epoch is one launch of eskf_run_kernel (the time loop in the kernel):
-    bit for bit the step-by-step run, also started from another handle's state, continued, and with shared streams."""
+    bit for bit the step-by-step run, also started from another handle's state, continued, and with shared streams.
+    (Between the steps of a run the covariances of a block's last round stay in LDS and the order of the rounds
+    alternates: every block size -- a quarter, a third, half, all of them resident -- and ragged batches.)"""
     env = dict(os.environ)
     for k in ("DVI_ESKF_PRE_LEGACY", "DVI_ESKF_FUSED", "DVI_ESKF_FUSED_ROUNDS", "DVI_ESKF_RUN", "DVI_ESKF_RUN_ROUNDS"):
         env.pop(k, None)
     if rounds:
         env["DVI_ESKF_RUN_ROUNDS"] = rounds
     env["DVI_ESKF_VERBOSE"] = "1"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_run_child.py"), str(batch), dtype, ROOT], cwd=ROOT,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_run_child.py"), str(batch), dtype, ROOT, str(steps)], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     assert "eskf_run_kernel" in p.stderr, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("batch,rounds,steps", [(777, "4", 17), (1000, "3", 16), (130, "2", 9)])
+def test_longer_runs_in_one_launch(batch, rounds, steps):
+    """the same comparison over more steps than a block has rounds, even and odd step counts"""
+    test_run_in_one_launch_equals_the_steps_one_by_one(batch, "f64", rounds, steps)
