@@ -20,6 +20,10 @@ namespace eskf { hipError_t x_read_stamps(unsigned long long* out); hipError_t x
 namespace eskf { hipError_t x_read_run_stamps(unsigned long long* out); hipError_t x_read_pre_stamps(unsigned long long* out); }
 #endif
 
+#if defined(ESKF_X_EPDUMP) || defined(ESKF_X_EPSTAMPS)
+static unsigned long long* g_x_ep_buffer = nullptr;     // diagnostic builds: where the long-horizon kernel leaves its dump / stamps
+#endif
+
 struct dvi_eskf {
     int64_t B;
     int dtype;
@@ -47,6 +51,10 @@ struct dvi_eskf {
     hipStream_t side[2];
     hipEvent_t ev_fork, ev_join[2];
     bool side_ready;
+    // dvi_eskf_run_epochs through the long-horizon kernel: the schedule's predict counts on the device
+    int32_t* d_npred;
+    int64_t npred_cap;
+    std::vector<int32_t> npred_host;    // what d_npred holds (a run with the schedule of the run before uploads nothing)
 };
 
 namespace {
@@ -79,6 +87,10 @@ void free_buffers(dvi_eskf* h) {
     if (h->d_status) (void)hipFree(h->d_status);
     if (h->d_noise) (void)hipFree(h->d_noise);
     h->d_noise = nullptr;
+    if (h->d_npred) (void)hipFree(h->d_npred);
+    h->d_npred = nullptr;
+    h->npred_cap = 0;
+    h->npred_host.clear();
     h->d_P = h->d_x = h->d_J = h->d_e = nullptr;
     h->d_status = nullptr;
     h->jcap = 0;
@@ -92,6 +104,9 @@ bool alloc_buffers(dvi_eskf* h) {
     h->d_status = nullptr;
     h->d_aux = nullptr;
     h->jcap = 0;
+    h->d_npred = nullptr;
+    h->npred_cap = 0;
+    h->npred_host.clear();
     if (hipMalloc(&h->d_aux, B * (eskf::AUX_WORDS0 + eskf::AUX_WORDSK) * es) != hipSuccess ||
         hipMalloc(&h->d_P, B * 300 * es) != hipSuccess || hipMalloc(&h->d_x, B * 36 * es) != hipSuccess ||
         hipMalloc(&h->d_J, B * eskf::JAC_WORDS * es) != hipSuccess ||
@@ -273,6 +288,8 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     if (!h) return DVI_ESKF_ENOMEM;
     const size_t es = elem_size(src->dtype);
     h->d_noise = nullptr;             // (the struct copy aliased the source's buffers)
+    h->d_npred = nullptr;
+    h->npred_cap = 0;
     h->side_ready = false;            // (... and its streams: the copy makes its own when it needs them)
     if (!alloc_buffers(h)) {
         delete h;
@@ -503,6 +520,87 @@ int run_pairs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule*
     return 1;
 }
 
+// A run with epochs of any length as ONE launch of eskf_epochs_kernel (eskf_epochs.hip): the time loop of Filter.run and
+// the predicts of propagate_imu (Filter.py:144-217) inside the kernel, the covariances in registers from the first epoch
+// to the last.  Returns 1 if the run was enqueued that way, 0 if it has to go epoch by epoch (log rows, configurations
+// the kernel does not cover, a schedule that would have to be uploaded while the stream is being captured,
+// DVI_ESKF_EPOCHS=0), < 0 on error.
+int run_epochs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream) {
+    if (sc->rows_out) return 0;
+    if (sc->n_epochs > 0x7fffffffLL) return 0;
+    int64_t total = 0;
+    bool uniform = true;
+    for (int64_t e = 0; e < sc->n_epochs; ++e) {
+        total += sc->n_pred[e];
+        uniform = uniform && sc->n_pred[e] == sc->n_pred[0];
+    }
+    if (total > 0x7fffffffLL) return 0;
+    if (src == h) src = nullptr;
+    if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
+    DeviceGuard g(h->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipStream_t s = (hipStream_t)stream;
+    eskf::EpochsArgs ea;
+    std::memset(&ea, 0, sizeof ea);
+    eskf::StepArgs& a = ea.a;
+    a = base_args(h);
+    a.dt = sc->dt; a.om = sc->om; a.acc = sc->acc;
+    a.pos = sc->pos; a.quat = sc->quat_xyzw; a.notch = sc->notch;
+    a.status = sc->status;
+    a.n_pred = 0;
+    a.do_update = 1;
+    a.dt_stride = sc->dt_per_instance ? 1 : 0;
+    a.imu_stride = sc->imu_per_instance ? 1 : 0;
+    a.meas_stride = sc->meas_per_instance ? 1 : 0;
+    if (!eskf::epochs_kernel_block(h->dtype, h->lpi, a, h->hp)) return 0;
+    const bool capturing = stream_is_capturing(s);
+    if (!uniform) {
+        // the predict counts go to the device: an allocation (first time, or a longer schedule than any before) and a copy
+        // from pageable host memory -- neither can be recorded into a graph, nor may the buffer of a recorded launch move
+        const bool same = (int64_t)h->npred_host.size() == sc->n_epochs && h->d_npred &&
+                          std::memcmp(h->npred_host.data(), sc->n_pred, (size_t)sc->n_epochs * sizeof(int32_t)) == 0;
+        // (a recorded launch reads the buffer at every replay: once a run of the handle has been captured it is never written again)
+        if (!same && (capturing || h->captured)) return 0;
+        if (!same && sc->n_epochs > h->npred_cap) {
+            int32_t* nb = nullptr;
+            if (hipMalloc((void**)&nb, (size_t)sc->n_epochs * sizeof(int32_t)) != hipSuccess) return DVI_ESKF_ENOMEM;
+            if (h->d_npred) {
+                if (hipDeviceSynchronize() != hipSuccess) { (void)hipFree(nb); return DVI_ESKF_EHIP; }   // (an earlier run may still read it)
+                (void)hipFree(h->d_npred);
+            }
+            h->d_npred = nb;
+            h->npred_cap = sc->n_epochs;
+        }
+        // (stream-ordered behind the runs that read the buffer before; the source is the caller's host array, consumed
+        //  before this call returns: pageable memory is staged synchronously)
+        if (!same) {
+            h->npred_host.clear();
+            if (hipMemcpyAsync(h->d_npred, sc->n_pred, (size_t)sc->n_epochs * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) return DVI_ESKF_EHIP;
+            if (hipStreamSynchronize(s) != hipSuccess) return DVI_ESKF_EHIP;
+            h->npred_host.assign(sc->n_pred, sc->n_pred + sc->n_epochs);
+        }
+        ea.n_pred = h->d_npred;
+    }
+    if (capturing) h->captured = true;
+    a.pending_hint = (h->maybe_pending || h->captured) ? 1 : 0;
+    if (src) {
+        if (flush_pending(src, s) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+        a.P_src = src->d_P;
+        a.xs_src = src->d_x;
+        a.drop_pending = 1;
+    }
+#if defined(ESKF_X_EPDUMP) || defined(ESKF_X_EPSTAMPS)
+    ea.stamps = g_x_ep_buffer;
+#endif
+    ea.n_epochs = (int32_t)sc->n_epochs;
+    ea.n_total = (int32_t)total;
+    ea.n_uniform = uniform ? sc->n_pred[0] : -1;
+    if (eskf::launch_epochs(h->dtype, h->lpi, ea, h->hp, s) != hipSuccess) return DVI_ESKF_EHIP;
+    h->maybe_pending = true;        // the last epoch's update leaves its error state behind
+    h->jac_ip = -1;
+    return 1;
+}
+
 int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream);
 }  // namespace
 
@@ -532,6 +630,7 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
     if (src == h) src = nullptr;
     if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
     if (int one = run_pairs_in_one_launch(h, src, sc, stream)) return one < 0 ? one : DVI_ESKF_OK;
+    if (int one = run_epochs_in_one_launch(h, src, sc, stream)) return one < 0 ? one : DVI_ESKF_OK;
     {   // size the Jacobian workspace for the longest epoch once, not epoch by epoch
         int longest = 0;
         for (int64_t e = 0; e < sc->n_epochs; ++e) longest = sc->n_pred[e] > longest ? sc->n_pred[e] : longest;
@@ -763,6 +862,10 @@ int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, 
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
 
+#if defined(ESKF_X_EPDUMP) || defined(ESKF_X_EPSTAMPS)
+int dvi_eskf_x_ep_buffer(void* device_buffer) { g_x_ep_buffer = static_cast<unsigned long long*>(device_buffer); return 0; }
+void* dvi_eskf_x_raw_J(dvi_eskf* h) { return h ? h->d_J : nullptr; }
+#endif
 #ifdef ESKF_X_RUNSTAMPS
 int dvi_eskf_x_run_stamps(unsigned long long* out) { return eskf::x_read_run_stamps(out) == hipSuccess ? 0 : -4; }
 int dvi_eskf_x_pre_stamps(unsigned long long* out) { return eskf::x_read_pre_stamps(out) == hipSuccess ? 0 : -4; }

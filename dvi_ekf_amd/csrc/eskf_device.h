@@ -109,6 +109,26 @@ int step_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& h
 hipError_t launch_step_fused(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_run(int dtype, int lpi, const StepArgs& a, const RunArgs& ra, const HostParams& hp, hipStream_t stream);
 
+// A whole run of epochs -- n_pred[e] >= 0 predicts, then the update with measurement e -- in ONE launch of
+// eskf_epochs_kernel (eskf_epochs.hip): a block keeps its instances for the run, producer wavefronts run the nominal
+// recurrences and the Jacobian blocks ahead of the consumer wavefronts that hold the covariances in registers.  The
+// StepArgs describe epoch 0 / predict 0 (inputs as [total] / [n_epochs] arrays, strides as in StepArgs: predict g of the
+// run at g rows, epoch e's measurement and status words at e rows).
+struct EpochsArgs {
+    StepArgs a;
+    const int32_t* n_pred;   // DEVICE [n_epochs], or null when every epoch has n_uniform predicts
+    int32_t n_epochs;
+    int32_t n_total;         // sum of n_pred
+    int32_t n_uniform;
+    int32_t pad;
+    void* xlog;              // nullable [n_epochs][36][B]: the state record after every epoch's update, injected (log rows)
+    unsigned long long* stamps;   // diagnostic builds (ESKF_X_EPSTAMPS): [blocks][16 waves][8] cycle counters
+};
+// instances per block if the long-horizon kernel takes this run (shared noise model, default covariance kernel, no gain
+// output, no kept Jacobians, no gyro block in Q), else 0
+int epochs_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp);
+hipError_t launch_epochs(int dtype, int lpi, const EpochsArgs& ea, const HostParams& hp, hipStream_t stream);
+
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 bool epoch_sub_batches_ok(int lpi, int64_t sub_first, int64_t sub_count, int n_pred, bool per_instance_noise, bool gain_out, bool have_aux);

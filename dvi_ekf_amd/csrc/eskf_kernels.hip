@@ -40,6 +40,15 @@
 
 #include "eskf_device.h"
 
+// Where a*b+c becomes one fused operation is decided by the SOURCE -- within an expression, by the front end -- and not by
+// the back end's view of the code around it (hipcc's default, -ffp-contract=fast, lets the instruction selector fuse
+// across statements, depending on how often a product is used in whatever kernel the statement was inlined into).  The
+// same device function then yields the same bits in every kernel that uses it: the paths of DESIGN.md section 4 are
+// compared bit for bit with each other (tests/test_gpu_step_kernel.py, test_gpu_epochs_kernel.py), and a multi-GPU shard
+// must compute what the single GPU computes whichever kernel its batch size selects.  Functions that spell their
+// operations out (`#pragma clang fp contract(off)` + fma) are not affected.
+#pragma clang fp contract(on)
+
 namespace eskf {
 
 // ----------------------------------------------------------------------------------
@@ -1413,6 +1422,22 @@ __global__ __launch_bounds__(256, 4) void eskf_pre4_kernel(StepArgs a, DevParams
 // the post-predict dofs | then per predict k, 8 words from 12 + 8 k: q_old(k) 4 | notch+ 2 (angle, rate) | sin, cos phi+
 // ----------------------------------------------------------------------------------
 constexpr int AUX0 = 12, AUXK = 8;
+// position, velocity and camera position of one predict (equations.py:76-77,83-85), shared by eskf_nominal_kernel and the
+// long-horizon kernel (eskf_epochs.hip) with every fusion spelled out: where a*b+c is contracted must not depend on the
+// kernel the statement is inlined into -- the two paths are compared bit for bit
+template <typename T>
+__device__ __forceinline__ void advance_p_v_pc(T dt, const T (&acc_avg)[3], const T (&Rcr)[3], T (&p)[3], T (&v)[3], T (&pc)[3]) {
+#pragma clang fp contract(off)
+    const T h = dt * dt * T(0.5);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T vi = v[i];
+        const T dv = dt * vi;
+        p[i] = t_fma(h, acc_avg[i], p[i] + dv);                                 // equations.py:76
+        v[i] = t_fma(dt, acc_avg[i], vi);                                       // equations.py:77
+        pc[i] = t_fma(dt, Rcr[i], pc[i] + dv);                                  // equations.py:83-85
+    }
+}
 template <typename T, bool SIMU>
 __global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevParams<T> prm) {
     __shared__ T sX[9 * 64];                            // s1 c1 s2 c2 s3 c3 (pre-predict dofs) | p_cam after the last predict
@@ -1516,14 +1541,9 @@ __global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevPar
             for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);      // equations.py:47
             cross3(om_avg, k == 0 ? pB0 : pB1, cr);                                 // BB_v_CB == 0
             mat3_vec(R, cr, Rcr);
+            advance_p_v_pc(dt, acc_avg, Rcr, p, v, pc);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const T vi = v[i];
-                p[i] = p[i] + dt * vi + (dt * dt * T(0.5)) * acc_avg[i];            // equations.py:76
-                v[i] = vi + dt * acc_avg[i];                                        // equations.py:77
-                pc[i] = pc[i] + dt * vi + dt * Rcr[i];                              // equations.py:83-85
-                om_o[i] = om_n[i]; acc_o[i] = acc_n[i];                             // Filter.py:225-226
-            }
+            for (int i = 0; i < 3; ++i) { om_o[i] = om_n[i]; acc_o[i] = acc_n[i]; }  // Filter.py:225-226
             mat_to_quat(Rn, q);                                                     // state.py:67
             if (k + 1 < n && live) {
 #pragma unroll
@@ -2486,13 +2506,15 @@ template <int ROW>
 __device__ __forceinline__ void add_in_row_lanes(double& p, double q) {
     constexpr unsigned long long mask = (1ull << ROW) | (1ull << (32 + ROW));
     unsigned long long saved;
-    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask));
+    // (s_and_saveexec writes SCC: without the clobber a compare of the surrounding loop was scheduled in front of this
+    //  statement and its branch behind it -- the long-horizon kernel left its predict loop after the first predict)
+    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f64 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask) : "scc");
 }
 template <int ROW>
 __device__ __forceinline__ void add_in_row_lanes(float& p, float q) {
     constexpr unsigned long long mask = (1ull << ROW) | (1ull << (32 + ROW));
     unsigned long long saved;
-    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f32 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask));
+    asm("s_and_saveexec_b64 %1, %3\n\tv_add_f32 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask) : "scc");
 }
 template <typename T, bool PIN, bool GYRO = true, bool LANES32 = false>
 __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, const T* sN, int row, T (&p)[24]) {
@@ -4150,8 +4172,10 @@ __global__ __launch_bounds__(256) void eskf_jacobians_kernel(int64_t B, const T*
 // spills what does not fit (run kernel: 73 vector / 160 scalar registers spilled with it, 21 / 0 without; a step of
 // the run was slower than a launch per step).  The other kernels keep the pass: their loops over the predicts of an
 // epoch are what it is for.
+// A third translation unit, eskf_epochs.hip (the long-horizon kernel), includes this file with ESKF_TU_EPOCHS defined
+// for its device functions only: no launcher of this file is compiled there.
 // ----------------------------------------------------------------------------------
-#ifndef ESKF_TU_FUSED
+#if !defined(ESKF_TU_FUSED) && !defined(ESKF_TU_EPOCHS)
 template <typename T, int LPI, bool PIN = false>
 static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
@@ -4185,13 +4209,17 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     return hipGetLastError();
 }
 
-#endif  // !ESKF_TU_FUSED
+#endif  // !ESKF_TU_FUSED && !ESKF_TU_EPOCHS
 
+#ifndef ESKF_TU_EPOCHS
 // diagnostic switch (environment DVI_ESKF_PRE_LEGACY=1, read once): single-predict launches through the two-role
 // pre kernel instead of eskf_pre4_kernel -- the A/B of the two and the bitwise test of one against the other
 static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEGACY"); return e && e[0] == '1'; }();
+#endif
 
-#ifdef ESKF_TU_FUSED
+#if defined(ESKF_TU_EPOCHS)
+// (device functions only)
+#elif defined(ESKF_TU_FUSED)
 
 // The one-launch step (eskf_step_kernel).  DVI_ESKF_FUSED=0 switches it off (A/B against the two kernels, and the bitwise
 // test of one path against the other); DVI_ESKF_FUSED_ROUNDS=1..4 pins the block size (16 R instances).  Default: the
