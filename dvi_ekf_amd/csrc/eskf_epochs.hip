@@ -63,8 +63,8 @@ struct Lay {
     static constexpr int NIP = NI <= 4 ? 4 : NI <= 8 ? 8 : NI <= 16 ? 16 : 32;     // lanes per predict in the J wavefronts
     static constexpr int PPP = 64 / NIP < 4 ? 64 / NIP : 4;                        // predicts per J pass
     // ring depths: what fits next to the images (fp64, NC = 12: 115 KB of images)
-    static constexpr int D = NC > 8 ? (sizeof(T) == 8 ? 2 : 4) : NC > 4 ? 4 : 8;      // records
-    static constexpr int DA = NC > 8 ? (sizeof(T) == 8 ? 2 : 4) : 8;                  // aux entries
+    static constexpr int D = NC > 10 ? (sizeof(T) == 8 ? 2 : 4) : NC > 8 ? 4 : NC > 4 ? (sizeof(T) == 8 ? 4 : 6) : 8;      // records
+    static constexpr int DA = NC > 10 ? (sizeof(T) == 8 ? 2 : 4) : NC > 8 ? 4 : 8;                  // aux entries
     static constexpr int O_IMG = 0;
     static constexpr int O_RING = O_IMG + NI * IMG;
     static constexpr int O_AUX = O_RING + D * NI * RW;
@@ -83,11 +83,11 @@ __device__ __forceinline__ int peek(const int* p) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 #ifdef ESKF_X_EPSTAMPS
-#define EP_WAIT_BEGIN() const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
-#define EP_WAIT_END(SLOT) wait_cycles[SLOT] += __builtin_amdgcn_s_memtime() - tw0_;
+#define EP_WAIT_BEGIN() { const unsigned long long tw0_ = __builtin_amdgcn_s_memtime();
+#define EP_WAIT_END(SLOT) wait_cycles[SLOT] += __builtin_amdgcn_s_memtime() - tw0_; }
 #else
-#define EP_WAIT_BEGIN()
-#define EP_WAIT_END(SLOT)
+#define EP_WAIT_BEGIN() {
+#define EP_WAIT_END(SLOT) }
 #endif
 __device__ __forceinline__ void wait_ge(const int* p, int need) {
     while (peek(p) < need) __builtin_amdgcn_s_sleep(1);
@@ -97,6 +97,11 @@ __device__ __forceinline__ void wait_ge(const int* p, int need) {
 __device__ __forceinline__ bool all_ge(const int* counters, int n, int need, int lane) {
     const int v = __hip_atomic_load(counters + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_ballot_w64(v < need) == 0ull;
+}
+// some counter of counters[0..n) >= need
+__device__ __forceinline__ bool any_ge(const int* counters, int n, int need, int lane) {
+    const int v = __hip_atomic_load(counters + (lane < n ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_ballot_w64(v >= need) != 0ull;
 }
 __device__ __forceinline__ void wait_all_ge(const int* counters, int n, int need, int lane) {
     while (!all_ge(counters, n, need, lane)) __builtin_amdgcn_s_sleep(1);
@@ -137,23 +142,34 @@ __device__ __forceinline__ void load_sample(const StepArgs& a, int g, int g_end,
 // the mailbox afterwards (what this run's own update of the epoch before has put there)
 template <typename T>
 struct Pending {
-    const T* src;       // 24 words
+    T src[24];          // (the words a role uses: the others are never loaded)
     int status;
     bool inject;
 };
-template <typename T>
+// FIRST / COUNT...: the word ranges the calling role needs (up to three)
+template <typename T, int F0, int N0, int F1, int N1, int F2 = 0, int N2 = 0, int F3 = 0, int N3 = 0>
 __device__ __forceinline__ Pending<T> pending_of(const StepArgs& a, int e, int64_t b, const T* mb, const int* flags, int nca, int lane) {
     Pending<T> pd;
+    auto take = [&](const T* src) {
+#pragma unroll
+        for (int i = 0; i < N0; ++i) pd.src[F0 + i] = src[F0 + i];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) pd.src[F1 + i] = src[F1 + i];
+#pragma unroll
+        for (int i = 0; i < N2; ++i) pd.src[F2 + i] = src[F2 + i];
+#pragma unroll
+        for (int i = 0; i < N3; ++i) pd.src[F3 + i] = src[F3 + i];
+    };
     if (e == 0) {
-        pd.src = reinterpret_cast<const T*>(a.e) + b * 24;
         pd.status = a.pending_hint ? a.status_ws[b] : 0;
         const bool was = (pd.status & DVI_STATUS_PENDING) != 0;
         pd.inject = was && !a.drop_pending && !(pd.status & DVI_STATUS_SINGULAR);
+        if (pd.inject) take(reinterpret_cast<const T*>(a.e) + b * 24);
     } else {
         wait_all_ge(flags + F_CEPOCH, nca, e, lane);
-        pd.src = mb + MB_E;
         pd.status = word_as_status(mb[MB_ST]);
         pd.inject = (pd.status & DVI_STATUS_PENDING) != 0 && !(pd.status & DVI_STATUS_SINGULAR);
+        take(mb + MB_E);
     }
     return pd;
 }
@@ -200,8 +216,9 @@ __device__ __forceinline__ void role_ra(const EpochsArgs& A, const DevParams<T>&
         }
         T dt, om_n[3], acc_n[3];
         load_sample(a, g, g_end, b, dt, om_n, acc_n);
+        Pending<T> pd;
         EP_WAIT_BEGIN()
-        const Pending<T> pd = pending_of<T>(a, e, b, mb, flags, nca, lane);
+        pd = pending_of<T, 0, 15, 18, 3>(a, e, b, mb, flags, nca, lane);
         EP_WAIT_END(0)
         if (pd.inject) {                                // state.py:46-60,105-129
             T e15[15], e1821[3];
@@ -353,8 +370,17 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
         }
         T dt, om_n[3], acc_n[3];
         load_sample(a, g, g_end, b, dt, om_n, acc_n);
+        Pending<T> pd;
+        T qm[4];                                                                        // Filter.py:364-365
+        {   // (depends on the measurement only: evaluated before the wait for the update)
+            T nq[4] = {T(0), T(0), T(0), T(1)};
+            t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
+            quat_mul(nq, qraw, qm);
+            quat_nrm(qm);
+            qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
+        }
         EP_WAIT_BEGIN()
-        const Pending<T> pd = pending_of<T>(a, e, b, mb, flags, nca, lane);
+        pd = pending_of<T, 6, 3, 11, 1, 15, 3, 21, 3>(a, e, b, mb, flags, nca, lane);
         EP_WAIT_END(0)
         if (pd.inject) {
             T e69[3], e1518[3], e2124[3], e11 = pd.src[11];
@@ -369,14 +395,6 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
 #pragma unroll
             for (int i = 0; i < 3; ++i) notch[i] += e1518[i];
             q3 += e11;
-        }
-        T qm[4];                                                                        // Filter.py:364-365
-        {
-            T nq[4] = {T(0), T(0), T(0), T(1)};
-            t_sincos(T(0.5) * ang_notch, nq[2], nq[3]);          // Quaternion(val=[0,0,ang], euler="xyz")
-            quat_mul(nq, qraw, qm);
-            quat_nrm(qm);
-            qm[0] = -qm[0]; qm[1] = -qm[1]; qm[2] = -qm[2];      // conjugate
         }
         EP_WAIT_BEGIN()
         wait_ge(flags + F_RA_CONST, e + 1);
@@ -487,27 +505,27 @@ __device__ __forceinline__ void role_j(const EpochsArgs& A, const DevParams<T>& 
     const T sig_om[3] = {prm.sig_om[0], prm.sig_om[1], prm.sig_om[2]};
     int g0 = 0;
     while (g0 < A.n_total) {
-        // how many predicts this pass takes: what the recurrences have published, what the ring has room for
+        // How many predicts this pass takes: what the recurrences have published, what the ring has room for -- and, while
+        // no covariance wavefront is about to run out of records, not fewer than a full pass (PPP predicts, one per group of
+        // NIP lanes: a pass costs the same instructions whether one group works or all of them, and with the ring full the
+        // wavefront would otherwise wake up for every single slot that becomes free).
         int n;
         {
+            const int n_target = A.n_total - g0 < PPP ? A.n_total - g0 : PPP;
             EP_WAIT_BEGIN()
             for (;;) {
                 int have = peek(flags + F_RA);
                 if (WHICH) { const int hb = peek(flags + F_RB); have = hb < have ? hb : have; }
                 n = have - g0;
-                if (n > 0) break;
+                n = n < n_target ? n : n_target;
+                // record g lies in slot g % D: free once every covariance wavefront has taken record g - D
+                while (n > 0 && !all_ge(flags + F_LOADED, nca, g0 + n - D, lane)) --n;
+                if (n >= n_target) break;
+                // (somebody has at most one record left in front of it -- g0 - 1 is the last one published: do not let it wait)
+                if (n > 0 && any_ge(flags + F_LOADED, nca, g0 - 1, lane)) break;
                 __builtin_amdgcn_s_sleep(1);
             }
             EP_WAIT_END(0)
-            n = n < PPP ? n : PPP;
-            EP_WAIT_BEGIN()
-            for (;;) {      // record g lies in slot g % D: free once every covariance wavefront has taken record g - D
-                while (n > 0 && !all_ge(flags + F_LOADED, nca, g0 + n - D, lane)) --n;
-                if (n > 0) break;
-                n = 1;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            EP_WAIT_END(1)
             asm volatile("" ::: "memory");
         }
         if (lane_ok && ps < n) {
@@ -552,6 +570,38 @@ __device__ __forceinline__ void role_j(const EpochsArgs& A, const DevParams<T>& 
         g0 += n;
         if (lane == 0) publish(flags + (WHICH ? F_JB : F_JA), g0);
     }
+}
+
+// P' += Fi Q Fi^T on the row-resident P (Filter.py:263-264,349): diagonal entries 3..14 <- Q[i - 3], 17 <- Q[12], each
+// added in the two lanes that own the row -- the adds of rowk::noise_rows under the same constant lane sets, but with
+// EXEC written directly (two scalar moves of an inline constant per entry and one restore at the end instead of a mask
+// pair, a save and a restore per entry: 40 instructions instead of 65 -- at one covariance wavefront per SIMD every
+// instruction of whatever kind is a slot of the wavefront's own time).  All lanes are active on entry.
+__device__ __forceinline__ void noise_diag_exec(const DevParams<double>& prm, double (&p)[24]) {
+#define EP_NQ(K, ROW) "s_mov_b32 exec_lo, %[m" #ROW "]\n s_mov_b32 exec_hi, %[m" #ROW "]\n v_add_f64 %[p" #ROW "], %[p" #ROW "], %[q" #K "]\n"
+    asm volatile(EP_NQ(0, 3) EP_NQ(1, 4) EP_NQ(2, 5) EP_NQ(3, 6) EP_NQ(4, 7) EP_NQ(5, 8) EP_NQ(6, 9) EP_NQ(7, 10) EP_NQ(8, 11) EP_NQ(9, 12)
+                 EP_NQ(10, 13) EP_NQ(11, 14) EP_NQ(12, 17) "s_mov_b64 exec, -1\n"
+                 : [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]), [p8] "+v"(p[8]), [p9] "+v"(p[9]),
+                   [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p17] "+v"(p[17])
+                 : [q0] "s"(prm.qd[0]), [q1] "s"(prm.qd[1]), [q2] "s"(prm.qd[2]), [q3] "s"(prm.qd[3]), [q4] "s"(prm.qd[4]), [q5] "s"(prm.qd[5]),
+                   [q6] "s"(prm.qd[6]), [q7] "s"(prm.qd[7]), [q8] "s"(prm.qd[8]), [q9] "s"(prm.qd[9]), [q10] "s"(prm.qd[10]), [q11] "s"(prm.qd[11]),
+                   [q12] "s"(prm.qd[12]),
+                   [m3] "n"(1 << 3), [m4] "n"(1 << 4), [m5] "n"(1 << 5), [m6] "n"(1 << 6), [m7] "n"(1 << 7), [m8] "n"(1 << 8), [m9] "n"(1 << 9),
+                   [m10] "n"(1 << 10), [m11] "n"(1 << 11), [m12] "n"(1 << 12), [m13] "n"(1 << 13), [m14] "n"(1 << 14), [m17] "n"(1 << 17));
+#undef EP_NQ
+}
+__device__ __forceinline__ void noise_diag_exec(const DevParams<float>& prm, float (&p)[24]) {
+#define EP_NQ(K, ROW) "s_mov_b32 exec_lo, %[m" #ROW "]\n s_mov_b32 exec_hi, %[m" #ROW "]\n v_add_f32 %[p" #ROW "], %[p" #ROW "], %[q" #K "]\n"
+    asm volatile(EP_NQ(0, 3) EP_NQ(1, 4) EP_NQ(2, 5) EP_NQ(3, 6) EP_NQ(4, 7) EP_NQ(5, 8) EP_NQ(6, 9) EP_NQ(7, 10) EP_NQ(8, 11) EP_NQ(9, 12)
+                 EP_NQ(10, 13) EP_NQ(11, 14) EP_NQ(12, 17) "s_mov_b64 exec, -1\n"
+                 : [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]), [p8] "+v"(p[8]), [p9] "+v"(p[9]),
+                   [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p17] "+v"(p[17])
+                 : [q0] "s"(prm.qd[0]), [q1] "s"(prm.qd[1]), [q2] "s"(prm.qd[2]), [q3] "s"(prm.qd[3]), [q4] "s"(prm.qd[4]), [q5] "s"(prm.qd[5]),
+                   [q6] "s"(prm.qd[6]), [q7] "s"(prm.qd[7]), [q8] "s"(prm.qd[8]), [q9] "s"(prm.qd[9]), [q10] "s"(prm.qd[10]), [q11] "s"(prm.qd[11]),
+                   [q12] "s"(prm.qd[12]),
+                   [m3] "n"(1 << 3), [m4] "n"(1 << 4), [m5] "n"(1 << 5), [m6] "n"(1 << 6), [m7] "n"(1 << 7), [m8] "n"(1 << 8), [m9] "n"(1 << 9),
+                   [m10] "n"(1 << 10), [m11] "n"(1 << 11), [m12] "n"(1 << 12), [m13] "n"(1 << 13), [m14] "n"(1 << 14), [m17] "n"(1 << 17));
+#undef EP_NQ
 }
 
 // ---- C: the covariance of two instances, rows in registers for the whole run -------------------------------------
@@ -612,31 +662,48 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
     for (int e = 0; e < A.n_epochs; ++e) {
         const int n = n_pred_of(A, e);
         // ================================ predicts =======================================
+        // The record of predict g and the two counters that say whether it is complete come in ONE LDS round trip (the
+        // counters are read first: LDS executes a wavefront's reads in order, so a record read behind counters that say
+        // "complete" is the complete record), requested while the predict before is still computing its second Fx
+        // application; only a record that was not ready then is asked for again, polling.
+        T jn[3] = {T(0), T(0), T(0)};
+        int fa = 0, fb = 0;
+        auto fetch_record = [&](int gg) {
+            typedef const volatile __attribute__((address_space(3))) T lds_word_t;
+            typedef const volatile __attribute__((address_space(3))) int lds_flag_t;
+            const T* rec = ring + ((gg % D) * NI + ilc) * RW;
+            const int w0 = lig >= J_B0 ? lig - J_B0 : 0;
+            const int w2 = lig + 64 - J_B0 < RW - 1 ? lig + 64 - J_B0 : RW - 1;
+            fa = *(lds_flag_t*)(flags + F_JA);
+            fb = *(lds_flag_t*)(flags + F_JB);
+            // lane l holds words l, 32 + l, 64 + l of the 75-word record of the two-kernel path, whose words 0..7 are the
+            // residual; the ring keeps the 67 block words
+            jn[0] = *(lds_word_t*)(rec + w0);
+            jn[1] = *(lds_word_t*)(rec + (32 + lig - J_B0));
+            jn[2] = *(lds_word_t*)(rec + w2);
+        };
+        auto record_ready = [&](int gg) {
+            return __builtin_amdgcn_readfirstlane(fa) > gg && __builtin_amdgcn_readfirstlane(fb) > gg;
+        };
+        if (n > 0) fetch_record(g);
         for (int k = 0; k < n; ++k, ++g) {
             EP_WAIT_BEGIN()
-            wait_ge(flags + F_JA, g + 1);
-            wait_ge(flags + F_JB, g + 1);
-            EP_WAIT_END(0)
-            // the record: lane l holds words l, 32 + l, 64 + l of the 75-word record of the two-kernel path, whose words
-            // 0..7 are the residual; the ring keeps the 67 block words
-            T j0[3];
-            {
-                const T* rec = ring + ((g % D) * NI + ilc) * RW;
-                const int w0 = lig >= J_B0 ? lig - J_B0 : 0;
-                const int w2 = lig + 64 - J_B0 < RW - 1 ? lig + 64 - J_B0 : RW - 1;
-                j0[0] = rec[w0];
-                j0[1] = rec[32 + lig - J_B0];
-                j0[2] = rec[w2];
+            while (!record_ready(g)) {
+                __builtin_amdgcn_s_sleep(1);
+                fetch_record(g);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            EP_WAIT_END(0)
+            T j0[3] = {jn[0], jn[1], jn[2]};
+            asm volatile("" : "+v"(j0[0]), "+v"(j0[1]), "+v"(j0[2]) : : "memory");
             if (lane == 0) publish(flags + F_LOADED + cw, g + 1);
             JRegs<T> Jr;
 #pragma unroll
             for (int q = 0; q < 3; ++q) spread_rows(j0[q], Jr.X[q], Jr.Y[q]);
             fx_apply_store_dpp(Jr, p, sB + row * PS, active);      // column `row` of Fx P = row `row` of W = P Fx^T
             wave_sync();
+            if (k + 1 < n) fetch_record(g + 1);
             fx_apply_col_dpp(Jr, sB + row, p);                     // column `row` of Fx P Fx^T = row `row` of P'
-            noise_rows<T, false, false, true>(prm, nullptr, nullptr, row, p);
+            noise_diag_exec(prm, p);
             wave_sync();
         }
         // ================================ update ===========================================
@@ -713,6 +780,23 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
         {
             const bool upd = !fail;
             if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) ee = T(0);   // Filter.py:377-379
+            // The error state and the status word are final here: they go to the recurrences through the mailbox BEFORE the
+            // reset of the covariance, which then runs next to the injection (State.__add__) on the producer side; after the
+            // run's last update they go to memory, where the next call (or dvi_eskf_flush) finds them -- what the epochs
+            // enqueued one by one leave behind
+            {
+                const bool last = e + 1 == A.n_epochs;
+                if (valid) {
+                    if (lig < 24) mb[MB_E + lig] = upd ? ee : T(0);
+                    if (lig == 24) mb[MB_ST] = status_as_word(status | DVI_STATUS_PENDING, T(0));
+                    if (last && upd && active) reinterpret_cast<T*>(a.e)[inst * 24 + row] = ee;
+                    if (lig == 0) {
+                        if (last) a.status_ws[inst] = status | DVI_STATUS_PENDING;
+                        if (a.status) a.status[(int64_t)e * a.B + inst] = status;
+                    }
+                }
+                if (lane == 0) publish(flags + F_CEPOCH + cw, e + 1);
+            }
             T Gt[3], Gc[3];
             {
                 T Xe, Ye;
@@ -783,20 +867,6 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
                 gather_row_masked(va_, vb_, p);
                 wave_sync();
             }
-            // the error state and the status word: to the recurrences through the mailbox; after the run's last update
-            // to memory, where the next call (or dvi_eskf_flush) finds them -- what the epochs enqueued one by one leave behind
-            const bool last = e + 1 == A.n_epochs;
-            if (valid) {
-                if (lig < 24) mb[MB_E + lig] = upd ? ee : T(0);
-                if (lig == 24) mb[MB_ST] = status_as_word(status | DVI_STATUS_PENDING, T(0));
-                if (last && upd && active) reinterpret_cast<T*>(a.e)[inst * 24 + row] = ee;
-                if (lig == 0) {
-                    if (last) a.status_ws[inst] = status | DVI_STATUS_PENDING;
-                    if (a.status) a.status[(int64_t)e * a.B + inst] = status;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) publish(flags + F_CEPOCH + cw, e + 1);
         }
     }
     // ---- store: rows -> LDS in the order of the packed record -> the record as a straight copy ------------------------
@@ -831,8 +901,21 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
 
 }  // namespace ep
 
+// Which wavefront of the block does what.  A block's wavefronts go to the CU's four SIMDs in turn.  With two covariance
+// wavefronts per block (the small batches, where a covariance wavefront's latency is all there is) the block has eight
+// wavefronts of which two leave at once, so that each covariance wavefront has a SIMD to itself and the four producers
+// share the other two: 0 C0 | 1 C1 | 2 RA | 3 RB | 4, 5 - | 6 JA | 7 JB.  Larger blocks: 0 RA | 1 RB | 2 JA | 3 JB | 4.. C.
+template <int NC> struct Waves { static constexpr int N = NC == 2 ? 8 : NC + 4; };
+template <int NC>
+__device__ __forceinline__ int wave_role(int wave) {       // 0 RA, 1 RB, 2 JA, 3 JB, 4 + w: covariance wavefront w, -1: none
+    if constexpr (NC == 2) return wave < 2 ? 4 + wave : wave < 4 ? wave - 2 : wave < 6 ? -1 : wave - 4;
+    else return wave;
+}
+#ifndef ESKF_EP_F32_WAVES
+#define ESKF_EP_F32_WAVES 4
+#endif
 template <typename T, int NC>
-__global__ __launch_bounds__((NC + 4) * 64, 4) void eskf_epochs_kernel(EpochsArgs A, DevParams<T> prm) {
+__global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8) ? ESKF_EP_F32_WAVES : 4) void eskf_epochs_kernel(EpochsArgs A, DevParams<T> prm) {
     using L = ep::Lay<T, NC>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
@@ -852,14 +935,17 @@ __global__ __launch_bounds__((NC + 4) * 64, 4) void eskf_epochs_kernel(EpochsArg
 #ifdef ESKF_X_EPSTAMPS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
-    if (wave == 0) ep::role_ra<T, NC>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
-    else if (wave == 1) ep::role_rb<T, NC>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
-    else if (wave == 2) ep::role_j<T, NC, 0>(A, prm, lds, lane, nca, wait_cycles);
-    else if (wave == 3) ep::role_j<T, NC, 1>(A, prm, lds, lane, nca, wait_cycles);
-    else if (wave - 4 < nca) ep::role_c<T, NC>(A, prm, lds, wave - 4, lane, b0, ni, wait_cycles);
+    // (the recurrences and the Jacobian blocks are what the covariance wavefronts wait for: they go first on their SIMDs)
+    const int role = wave_role<NC>(wave);
+    if (role >= 0 && role < 4) __builtin_amdgcn_s_setprio(2);
+    if (role == 0) ep::role_ra<T, NC>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
+    else if (role == 1) ep::role_rb<T, NC>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
+    else if (role == 2) ep::role_j<T, NC, 0>(A, prm, lds, lane, nca, wait_cycles);
+    else if (role == 3) ep::role_j<T, NC, 1>(A, prm, lds, lane, nca, wait_cycles);
+    else if (role >= 4 && role - 4 < nca) ep::role_c<T, NC>(A, prm, lds, role - 4, lane, b0, ni, wait_cycles);
 #ifdef ESKF_X_EPSTAMPS
     if (A.stamps && (threadIdx.x & 63) == 0) {
-        unsigned long long* s = A.stamps + ((size_t)blockIdx.x * 16 + wave) * 8;
+        unsigned long long* s = A.stamps + ((size_t)blockIdx.x * 16 + (role < 0 ? 15 : role)) * 8;
         s[0] = __builtin_amdgcn_s_memtime() - t_begin;
         for (int k = 0; k < 4; ++k) s[1 + k] = wait_cycles[k];
         s[5] = __builtin_amdgcn_s_memrealtime();
@@ -881,14 +967,18 @@ static int n_compute_units() {
     }();
     return n_cu;
 }
-// covariance wavefronts per block: the smallest block that still gives every CU at most one (fp32: two) blocks -- a
-// small batch is spread over the whole chip, every covariance wavefront with a SIMD to itself -- up to the twelve that fit
-// next to the four producers
-static int epochs_nc(int64_t B, int dtype) {
-    if (g_epochs_nc == 2 || g_epochs_nc == 4 || g_epochs_nc == 8 || g_epochs_nc == 12) return g_epochs_nc;
-    const int64_t slots = (int64_t)n_compute_units() * (dtype == 0 ? 1 : 2);
-    for (int nc : {2, 4, 8}) if ((B + 2 * nc - 1) / (2 * nc) <= slots) return nc;
-    return dtype == 0 ? 12 : 8;
+// Covariance wavefronts per block.  A small batch is spread over the whole chip -- the smallest block that still gives every
+// CU at most one block: with two covariance wavefronts per block each has a SIMD to itself -- up to the twelve that fit next
+// to the four producers.  Measured on config #5's schedule (tools/sweep_epochs_nc.sh, us per camera frame, fp32 / fp64, one
+// generation of blocks): NC = 2 38 / 41, 4 49 / 52, 8 64 / 74, 10 73 / 87, 12 78 / 93 -- against 69-94 / 79-119 for the same
+// batches enqueued epoch by epoch.  Beyond one generation of twelve-wavefront blocks (B > 24 CUs) the epoch-by-epoch path is
+// the faster one (its lane-per-instance kernels work with all 64 lanes of a wavefront, the producers here with 2 NC of them)
+// and the launcher leaves the run to it unless DVI_ESKF_EPOCHS=1 asks for this kernel; 0 = the kernel serves nothing.
+static int epochs_nc(int64_t B) {
+    if (g_epochs_nc == 2 || g_epochs_nc == 4 || g_epochs_nc == 8 || g_epochs_nc == 10 || g_epochs_nc == 12) return g_epochs_nc;
+    const int64_t cus = n_compute_units();
+    for (int nc : {2, 4, 8, 10, 12}) if ((B + 2 * nc - 1) / (2 * nc) <= cus) return nc;
+    return g_epochs == 1 ? 12 : 0;
 }
 template <typename T>
 static int epochs_kernel_block_typed(int lpi, const StepArgs& a, const DevParams<T>& prm) {
@@ -900,7 +990,7 @@ static int epochs_kernel_block_typed(int lpi, const StepArgs& a, const DevParams
     }();
     const bool ok = lds_ok && g_epochs != 0 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 &&
                     a.B < 0x7fffffffLL;
-    return ok ? 2 * epochs_nc(a.B, sizeof(T) == 8 ? 0 : 1) : 0;
+    return ok ? 2 * epochs_nc(a.B) : 0;
 }
 int epochs_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
     if (dtype == 0) return epochs_kernel_block_typed<double>(lpi, a, make_dev_params<double>(hp));
@@ -915,7 +1005,7 @@ static hipError_t launch_epochs_nc(const EpochsArgs& ea, const DevParams<T>& prm
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
     (void)attr;
     const unsigned blocks = (unsigned)((ea.a.B + L::NI - 1) / L::NI);
-    hipLaunchKernelGGL((eskf_epochs_kernel<T, NC>), dim3(blocks), dim3((NC + 4) * 64), L::BYTES, stream, ea, prm);
+    hipLaunchKernelGGL((eskf_epochs_kernel<T, NC>), dim3(blocks), dim3(Waves<NC>::N * 64), L::BYTES, stream, ea, prm);
     return hipGetLastError();
 }
 template <typename T>
@@ -932,6 +1022,7 @@ static hipError_t launch_epochs_typed(int lpi, const EpochsArgs& ea, const DevPa
         case 4: return launch_epochs_nc<T, 2>(ea, prm, stream);
         case 8: return launch_epochs_nc<T, 4>(ea, prm, stream);
         case 16: return launch_epochs_nc<T, 8>(ea, prm, stream);
+        case 20: return launch_epochs_nc<T, 10>(ea, prm, stream);
         case 24: return launch_epochs_nc<T, 12>(ea, prm, stream);
         default: return hipErrorInvalidValue;
     }

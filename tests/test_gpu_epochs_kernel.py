@@ -23,6 +23,7 @@ def _child(batch, dtype, sched, nc="", frozen="000000", hold="1", timeout=600):
         env.pop(k, None)
     if nc:
         env["DVI_ESKF_EPOCHS_NC"] = nc
+    env["DVI_ESKF_EPOCHS"] = "1"        # (also where the launcher would leave a batch of this size to the epoch-by-epoch path)
     env["DVI_ESKF_VERBOSE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_epochs_child.py"), str(batch), dtype, ROOT, sched, frozen, hold], cwd=ROOT,
                        env=env, capture_output=True, text=True, timeout=timeout)
@@ -31,7 +32,7 @@ def _child(batch, dtype, sched, nc="", frozen="000000", hold="1", timeout=600):
 
 
 @pytest.mark.parametrize("batch,dtype,nc", [(5, "f64", ""), (5, "f32", ""), (1000, "f64", ""), (1000, "f32", ""), (1000, "f64", "2"), (1000, "f64", "12"),
-                                            (1000, "f32", "8"), (333, "f64", "4"), (8192, "f64", ""), (8192, "f32", "")])
+                                            (1000, "f32", "8"), (333, "f64", "4"), (700, "f32", "10"), (8192, "f64", ""), (8192, "f32", "")])
 def test_run_of_epochs_in_one_launch_equals_the_epochs_one_by_one(batch, dtype, nc):
     """the ragged 33 / 33 / 34 schedule of BASELINE config #5 (three camera frames), every block size"""
     _child(batch, dtype, "33,33,34", nc)

@@ -1,10 +1,16 @@
+"""BASELINE config #5's schedule (33 / 33 / 34 predicts per update, shared IMU stream) over batch and precision: microseconds
+per camera frame and IMU steps per second of one dvi_eskf_run_epochs call.  Run once per setting of DVI_ESKF_EPOCHS
+(0: epoch by epoch -- three launches per frame --, default: the long-horizon kernel) / DVI_ESKF_EPOCHS_NC.
+usage: sweep_config5.py [batches, comma-separated] [n_steps]"""
 import os, sys, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dvi_ekf_amd.workloads import long_horizon
 dev = torch.device("cuda:0")
-for B in (1024, 2048, 4096, 8192, 16384):
-    wl = long_horizon(batch=B, n_steps=2000)
+batches = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1024, 2048, 4096, 8192, 16384]
+n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+for B in batches:
+    wl = long_horizon(batch=B, n_steps=n_steps)
     for dtype in (torch.float32, torch.float64):
         om, acc = wl.synthesize_imu_on_device(dtype=dtype, device=dev)
         om, acc = om[1:].contiguous(), acc[1:].contiguous()
@@ -21,4 +27,6 @@ for B in (1024, 2048, 4096, 8192, 16384):
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1) * 1e-3)
         tt = min(times[1:])
-        print(os.environ.get("DVI_ESKF_EPOCH_STREAMS", "1"), B, str(dtype)[-7:], "us/frame %.1f" % (tt / len(wl.n_pred) * 1e6), "IMU steps/s %.3e" % (B * wl.n_steps / tt), flush=True)
+        print(json.dumps({"epochs_kernel": os.environ.get("DVI_ESKF_EPOCHS", "default"), "nc": os.environ.get("DVI_ESKF_EPOCHS_NC", "auto"), "B": B,
+                          "dtype": str(dtype)[-7:], "us_per_frame": round(tt / len(wl.n_pred) * 1e6, 1), "imu_steps_per_s": float("%.4g" % (B * wl.n_steps / tt)),
+                          "finite": bool(torch.isfinite(f.x).all())}), flush=True)
