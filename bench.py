@@ -53,13 +53,23 @@ LOOP_IN_KERNEL_DEFAULT = True   # see --loop-in-kernel
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-def cpu_baseline(wl, seconds_target=12.0):
+def cpu_baseline(wl, seconds_target=12.0, threads=None):
     """Times the C oracle (oracle/eskf_oracle.c, OpenMP over instances) on a bounded sample
-    of the same workload: the first n instances, the first `horizon` pair-steps."""
+    of the same workload: the first n instances, the first `horizon` pair-steps.  threads: OpenMP threads
+    (None = all host cores)."""
     from oracle import c_oracle
     prm = c_oracle.make_params(wl.cfg.model.length, wl.cfg.model.angle, wl.cfg.frozen_dofs, True, wl.sigma_a,
                                wl.sigma_om, wl.Q, wl.R)
-    cores = c_oracle.num_threads()
+    all_cores = c_oracle.num_threads()
+    cores = c_oracle.set_num_threads(threads) if threads else all_cores
+    try:
+        return _cpu_baseline_run(c_oracle, prm, wl, seconds_target, cores)
+    finally:
+        if threads:
+            c_oracle.set_num_threads(all_cores)
+
+
+def _cpu_baseline_run(c_oracle, prm, wl, seconds_target, cores):
     H = wl.horizon
 
     def run(n, steps):
@@ -83,6 +93,147 @@ def cpu_baseline(wl, seconds_target=12.0):
     return {"value": n * steps / t, "unit": "pair-steps/s", "cores": cores, "kind": "port",
             "sample": f"C oracle (oracle/eskf_oracle.c, OpenMP), first {n} instances x {steps} pair-steps of the "
                       f"same workload, {t:.1f} s"}
+
+
+# ---- the `secondary` block: BASELINE's other configurations in the driver-run line ------------------------------------
+# algorithmic bytes and floating-point operations of the covariance arithmetic as the kernels perform it
+# (structure of Fx exploited; counted from the instruction lists of fx_apply_store_dpp / fx_apply_col_dpp / the update
+# of cov_rows_body, per instance: 24 rows x (74 + 71 FMA + 10 adds) + 13 noise adds per predict; 7 measurements x
+# (24 row FMAs + pivot, gain and error-estimate arithmetic) + the reset per update).  The lane-per-instance chains
+# (nominal state, Jacobian blocks: ~1.2k operations per predict) are not counted.
+BYTES_PREDICT = {"f64": 5432, "f32": 2716}
+FLOP_PER_PREDICT = 7213
+FLOP_PER_UPDATE = 12492
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 78.6}       # MI355X_MICROARCH.md: vector fp64 78.6 TF; fp32 at the same rate unless packed (157.3)
+
+
+def _flop_roofline(predicts_per_s, updates_per_s, dtype):
+    tf = (predicts_per_s * FLOP_PER_PREDICT + updates_per_s * FLOP_PER_UPDATE) / 1e12
+    return {"bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS[dtype],
+            "flop_per_predict": FLOP_PER_PREDICT, "flop_per_update": FLOP_PER_UPDATE,
+            "note": "covariance arithmetic only, as performed (Fx block structure exploited); resident regime: P stays on chip across "
+                    "the predicts, so no HBM fraction is claimed (SURVEY 8(d)); fp32 peak quoted unpacked (packed: 157.3)"}
+
+
+def secondary_block(dev, measure_pairs):
+    """Configs #3 and #5, the reference's 10:1 schedule and one GPU's share of config #4 at 8 GPUs, each with its formula
+    and its fraction of the roof that bounds it -- measured here so that they are in the line the driver records, not in a
+    file of the builder's.  Bounded: about a minute and a half on top of the headline measurement."""
+    from dvi_ekf_amd.workloads import long_horizon, monte_carlo_pairs
+    from dvi_ekf_amd.batch import BatchedESKF
+    from dvi_ekf_amd.workloads import default_run_inputs
+    from dvi_ekf_amd import noise
+    out = {}
+    t_start = time.perf_counter()
+
+    def events(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    # -- config #3: predict-only, B = 1 048 576, fp32, 256 consecutive launches (P round-trips HBM every launch)
+    B3 = 1048576
+    cfg, ri, Q, R, sa, so = default_run_inputs(golden_compat=True, all_frames=False, frozen=(0,) * 6)
+    f = BatchedESKF(B3, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=(0,) * 6, sigma_a=sa, sigma_om=so, hold_frozen=True,
+                    dtype=torch.float32, device=dev)
+    f.set_noise(Q, R)
+    f.set_state(x=np.tile(ri.x0, (B3, 1)), P=ri.P0, om_old=np.tile(ri.om0, (B3, 1)), acc_old=np.tile(ri.acc0, (B3, 1)))
+    z = noise.randn(3 << 32, 0, B3, 0, 1, 6, dtype=torch.float32, device=dev)[0]                # SURVEY 8(d): seed 3
+    om3, acc3 = (0.05 * z[:, 0:3]).contiguous(), (1.0 * z[:, 3:6]).contiguous()
+    dt3 = torch.full((B3,), 1e-3, device=dev, dtype=torch.float32)
+    t3 = events(lambda: f.predict(dt3, om3, acc3), 256, warm=8)
+    out["config3_predict_only_fp32"] = {
+        "batch": B3, "launches": 256, "ms_per_launch": t3 * 1e3, "value": B3 / t3, "unit": "predict-steps/s",
+        "roofline": {"bound": "hbm", "achieved": B3 * BYTES_PREDICT["f32"] / t3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": B3 * BYTES_PREDICT["f32"] / t3 / 1e9 / HBM_PEAK_GBS, "bytes_per_predict": BYTES_PREDICT["f32"],
+                     "formula": "2*300w + 2*36w + 7w, w = 4"},
+        "finite": bool(torch.isfinite(f.x).all())}
+    del f, z, om3, acc3, dt3
+    torch.cuda.empty_cache()
+
+    # -- the reference's own 10:1 schedule (do_fast_sim: false), fp64, B = 65 536: ten predicts (dt = 0.1) + one update per epoch
+    B10, N10 = 65536, 10
+    wl = monte_carlo_pairs(B10, horizon=4, seed=4, device=dev)
+    f = wl.make_filter()
+    snap = f.clone()
+    dt10 = torch.full((N10,), 0.1, device=dev, dtype=torch.float64)
+    om10 = wl.om[0].unsqueeze(0).repeat(N10, 1, 1).contiguous()
+    acc10 = wl.acc[0].unsqueeze(0).repeat(N10, 1, 1).contiguous()
+    k = [0]
+
+    def one_epoch():
+        f.epoch(dt10, om10, acc10, wl.pos[k[0] % 4], wl.quat[k[0] % 4], wl.notch[k[0] % 4])
+        k[0] += 1
+    best = None
+    for _ in range(2):
+        f.copy_state_from(snap)
+        k[0] = 0
+        t = events(one_epoch, 24, warm=0)
+        best = t if best is None else min(best, t)
+    byt = 5440 + 56 * N10
+    out["epochs_10to1_fp64"] = {
+        "batch": B10, "predicts_per_epoch": N10, "ms_per_epoch": best * 1e3, "value": B10 / best, "unit": "epochs/s",
+        "predict_steps_per_s": B10 * N10 / best, "launch_pattern": "one dvi_eskf_epoch call per epoch",
+        "roofline": _flop_roofline(B10 * N10 / best, B10 / best, "f64"),
+        "hbm_epoch_formula": {"bytes_per_epoch": byt, "formula": "2*300w + 2*36w + 7N*w + 8w, w = 8, N = 10", "achieved": B10 * byt / best / 1e9,
+                              "unit": "GB/s", "frac": B10 * byt / best / 1e9 / HBM_PEAK_GBS},
+        "finite": bool(torch.isfinite(f.x).all())}
+    del f, snap, wl, om10, acc10
+    torch.cuda.empty_cache()
+
+    # -- config #5: 1 kHz IMU / 30 Hz vision, 10 000 IMU steps, 33 / 33 / 34 predicts per update; B = 8 192 as specified and
+    #    B = 1 024, one GPU's share of it on 8 GPUs; the whole run is ONE dvi_eskf_run_epochs call
+    wl5 = long_horizon(batch=8192)
+    for name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        om, acc = wl5.synthesize_imu_on_device(dtype=dtype, device=dev)
+        om, acc = om[1:].contiguous(), acc[1:].contiguous()
+        tt = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=dev)
+        dt5, pos5, quat5, notch5 = tt(wl5.dt), tt(wl5.pos), tt(wl5.quat), tt(wl5.notch)
+        for B5 in (8192, 1024):
+            f = wl5.make_filter(dtype=dtype, device=dev, batch=B5)
+            snap = f.clone()
+            times, st = [], None
+            for _ in range(3):
+                f.copy_state_from(snap)
+                torch.cuda.synchronize(dev)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                st, _ = f.run_epochs(wl5.n_pred, dt5, om, acc, pos5, quat5, notch5)
+                e1.record()
+                torch.cuda.synchronize(dev)
+                times.append(e0.elapsed_time(e1) * 1e-3)
+            t5 = min(times[1:])
+            E5 = len(wl5.n_pred)
+            out["config5_%s_B%d" % (name, B5)] = {
+                "batch": B5, "imu_steps": wl5.n_steps, "updates": E5, "seconds_per_run": t5, "us_per_frame": t5 / E5 * 1e6,
+                "value": B5 * wl5.n_steps / t5, "unit": "IMU steps/s (instance-steps)",
+                "launch_pattern": "one dvi_eskf_run_epochs call for the whole run",
+                "regime": "camera noise 0.2 / 1 deg, frozen extrinsics (with the default YAML noise the reference filter stays bounded for ~800 steps only)",
+                "roofline": _flop_roofline(B5 * wl5.n_steps / t5, B5 * E5 / t5, name),
+                "skipped_updates": int((st & 1).sum()), "finite": bool(torch.isfinite(f.x).all())}
+            del f, snap
+        del om, acc
+    del wl5
+    torch.cuda.empty_cache()
+
+    # -- pair steps at B = 8 192: one GPU's share of config #4 (65 536 instances sharded over 8 GPUs)
+    m8 = measure_pairs(8192)
+    ach = BYTES_PER_PAIR_F64 * 8192 / (m8["kern_ms"] * 1e-3) / 1e9
+    out["pairs_fp64_B8192"] = {"batch": 8192, "value": 8192 / (m8["kern_ms"] * 1e-3), "unit": "pair-steps/s", "kernel_ms": m8["kern_ms"],
+                               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                            "bytes_per_pair": BYTES_PER_PAIR_F64,
+                                            "note": "in a run no covariance leaves the chip between the first and the last step at this batch: "
+                                                    "the algorithmic-bytes fraction is a throughput scale, not a traffic claim"},
+                               "valid": m8["ok"]}
+    out["seconds"] = time.perf_counter() - t_start
+    return out
 
 
 def parity_check(wl, steps=5, n=16):
@@ -141,6 +292,12 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="BASELINE config #4 as written: --batch is the TOTAL, sharded over the ranks (strong scaling); "
                          "the default keeps --batch instances per GPU (weak scaling, what the driver's scaling run expects)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling only: --batch instances per GPU.  With neither --weak nor --strong a job of N > 1 ranks measures "
+                         "BOTH in one run -- `value` is the strong-scaling figure (BASELINE's metric and config #4 read 'batch = 65 536 ... "
+                         "sharded'), the weak-scaling one is carried in `weak`")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` block (configs #3 and #5, the 10:1 schedule, the small batch, the 1-thread oracle)")
     ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
     ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident; 64/32/24/16/12/8 = LDS-image kernel with that many lanes per instance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -212,10 +369,13 @@ def main():
     from dvi_ekf_amd.workloads import monte_carlo_pairs
     B, H, K, W = args.batch, args.horizon, args.steps, args.warmup
     LOOP_IN_KERNEL = (args.loop_in_kernel == 1) if args.loop_in_kernel >= 0 else LOOP_IN_KERNEL_DEFAULT
-    if args.strong:
-        if B % world:
-            raise SystemExit("--strong: the total batch must divide evenly over the ranks")
-        B //= world
+    if args.strong and args.weak:
+        raise SystemExit("--strong and --weak exclude each other (neither: both are measured when N > 1)")
+    # which scaling modes this job measures: the one that was asked for; with N > 1 and no flag both -- first weak
+    # (--batch instances per GPU), then strong (--batch instances sharded over the ranks), which becomes `value`
+    modes = ["strong"] if args.strong else ["weak"] if (args.weak or world == 1) else ["weak", "strong"]
+    if "strong" in modes and args.batch % world:
+        raise SystemExit("strong scaling: the total batch must divide evenly over the ranks")
 
     backend = os.environ.get("DVI_BENCH_BACKEND", "nccl")   # "gloo" only for rehearsing the N>1 path on one GPU
 
@@ -353,104 +513,120 @@ def main():
                 n += 8 * H
             return n
 
-    run = Run(B, rank * B)
-    wl, f, status = run.wl, run.f, run.status
+    def measure(B):
+        """the contract's timed region for B instances on this rank: warm-up, EXACTLY K timed steps between barriers, MAX over ranks"""
+        run = Run(B, rank * B)
+        wl, f, status = run.wl, run.f, run.status
 
-    def all_gather_dofs(dofs):
-        if backend == "nccl":
-            dist.all_gather(gathered, dofs)                  # RCCL: the only collective on the path
+        def all_gather_dofs(dofs):
+            if backend == "nccl":
+                dist.all_gather(gathered, dofs)                  # RCCL: the only collective on the path
+            else:
+                host = [torch.empty((B, 6), dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(host, dofs.cpu())
+                for g_, h_ in zip(gathered, host):
+                    g_.copy_(h_)
+
+        run.eager(0, W)                                          # the W warm-up steps
+        gathered = None
+        run.read_calibration()                                   # (captures its graph: outside the timed region)
+        if dist is not None:   # warm the collective up as well
+            gathered = [torch.empty((B, 6), dtype=torch.float64, device=dev) for _ in range(world)]
+            all_gather_dofs(run.dofs)
+        torch.cuda.synchronize(dev)
+        ops = run.plan(K)                                        # (captures the graphs: outside the timed region)
+        # the first launch of an instantiated graph uploads it to the device (0.1-0.2 ms on these boxes, a fifth of a
+        # 20-step region): every graph of the timed region is launched once here, like the warm-up steps
+        seen = set()
+        for kind, g_, _n in ops:
+            if kind == "graph" and id(g_) not in seen:
+                seen.add(id(g_))
+                g_.replay()
+        torch.cuda.synchronize(dev)
+        sustained_steps = run.sustain(args.sustain_seconds)
+
+        barrier()
+        torch.cuda.synchronize(dev)
+        ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        t0 = time.perf_counter()
+        ev_t[0].record()                                         # HIP events on the launch stream around the K steps
+        run.execute(ops)
+        ev_t[1].record()
+        dofs = run.read_calibration()
+        if dist is not None:
+            all_gather_dofs(dofs)
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        graph = any(o[0] == "graph" for o in ops)
+        kern_ms = ev_t[0].elapsed_time(ev_t[1]) / K
+
+        if args.dump_dofs and rank == 0:
+            allv = torch.cat(gathered, dim=0) if gathered is not None else dofs
+            np.save(args.dump_dofs, allv.cpu().numpy())
+
+        # kernel time of one step from eagerly launched steps (diagnostic; contains the host's launch gaps).  With the time
+        # loop in the kernel an eager launch is a whole horizon (every launch of a run is: the profile summaries rely on it).
+        if args.mode == "pair" and LOOP_IN_KERNEL:
+            n_ev, per_ev = 2, H
         else:
-            host = [torch.empty((B, 6), dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(host, dofs.cpu())
-            for g_, h_ in zip(gathered, host):
-                g_.copy_(h_)
-
-    run.eager(0, W)                                          # the W warm-up steps
-    gathered = None
-    run.read_calibration()                                   # (captures its graph: outside the timed region)
-    if dist is not None:   # warm the collective up as well
-        gathered = [torch.empty((B, 6), dtype=torch.float64, device=dev) for _ in range(world)]
-        all_gather_dofs(run.dofs)
-    torch.cuda.synchronize(dev)
-    ops = run.plan(K)                                        # (captures the graphs: outside the timed region)
-    # the first launch of an instantiated graph uploads it to the device (0.1-0.2 ms on these boxes, a fifth of a
-    # 20-step region): every graph of the timed region is launched once here, like the warm-up steps
-    seen = set()
-    for kind, g_, _n in ops:
-        if kind == "graph" and id(g_) not in seen:
-            seen.add(id(g_))
-            g_.replay()
-    torch.cuda.synchronize(dev)
-    sustained_steps = run.sustain(args.sustain_seconds)
-
-    barrier()
-    torch.cuda.synchronize(dev)
-    ev_t = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    t0 = time.perf_counter()
-    ev_t[0].record()                                         # HIP events on the launch stream around the K steps
-    run.execute(ops)
-    ev_t[1].record()
-    dofs = run.read_calibration()
-    if dist is not None:
-        all_gather_dofs(dofs)
-    torch.cuda.synchronize(dev)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    graph = any(o[0] == "graph" for o in ops)
-    kern_ms = ev_t[0].elapsed_time(ev_t[1]) / K
-
-    if args.dump_dofs and rank == 0:
-        allv = torch.cat(gathered, dim=0) if gathered is not None else dofs
-        np.save(args.dump_dofs, allv.cpu().numpy())
-
-    # kernel time of one step from eagerly launched steps (diagnostic; contains the host's launch gaps).  With the time
-    # loop in the kernel an eager launch is a whole horizon (every launch of a run is: the profile summaries rely on it).
-    if args.mode == "pair" and LOOP_IN_KERNEL:
-        n_ev, per_ev = 2, H
-    else:
-        n_ev, per_ev = min(K, 2 * H), 1
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for k in range(n_ev):
-        ev[k][0].record()
-        run.eager(k * per_ev, per_ev)
-        ev[k][1].record()
-    torch.cuda.synchronize(dev)
-
-    # every instance must have done the full work: no singular / skipped updates, finite state
-    st = (run.status_run if (args.mode == "pair" and LOOP_IN_KERNEL) else status).cpu().numpy()
-    x_fin = f.x
-    ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
-    kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev])) / per_ev
-
-    # the same measurement at a batch whose working set does not fit the 256 MiB Infinity Cache (the headline
-    # batch's ~225 MB does): what the step sustains when it has to stream from HBM
-    streaming = None
-    if rank == 0 and world == 1 and dist is None and args.mode == "pair" and not args.no_streaming and not args.no_graph:
-        Bs = args.streaming_batch
-        del run.graphs
-        big = Run(Bs, 0)
-        nS = 4 * H
-        big.eager(0, H)
-        ops_s = big.plan(nS)
-        big.sustain(min(args.sustain_seconds, 0.2))
+            n_ev, per_ev = min(K, 2 * H), 1
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for k in range(n_ev):
+            ev[k][0].record()
+            run.eager(k * per_ev, per_ev)
+            ev[k][1].record()
         torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        big.execute(ops_s)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        ms = e0.elapsed_time(e1) / nS
-        ok_s = bool(((big.status_run if LOOP_IN_KERNEL else big.status).cpu().numpy() == 0).all())
-        ach = BYTES_PER_PAIR_F64 * Bs / (ms * 1e-3) / 1e9
-        streaming = {"batch": Bs, "steps": nS, "kernel_ms": ms, "pair_steps_per_s": Bs / (ms * 1e-3), "achieved": ach,
-                     "frac": ach / HBM_PEAK_GBS, "valid": ok_s,
-                     "note": "working set ~%d MB: streams from HBM (Infinity Cache 256 MiB)" % (Bs * 3450 // 1000000)}
-        del big
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+        # every instance must have done the full work: no singular / skipped updates, finite state
+        st = (run.status_run if (args.mode == "pair" and LOOP_IN_KERNEL) else status).cpu().numpy()
+        x_fin = f.x
+        ok = bool((st == 0).all()) and bool(torch.isfinite(x_fin).all())
+        kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev])) / per_ev
+
+        # the same measurement at a batch whose working set does not fit the 256 MiB Infinity Cache (the headline
+        # batch's ~225 MB does, DESIGN.md section 6): what the step sustains when it has to stream from HBM
+        streaming = None
+        if rank == 0 and world == 1 and dist is None and args.mode == "pair" and not args.no_streaming and not args.no_graph:
+            Bs = args.streaming_batch
+            del run.graphs
+            big = Run(Bs, 0)
+            nS = 4 * H
+            big.eager(0, H)
+            ops_s = big.plan(nS)
+            big.sustain(min(args.sustain_seconds, 0.2))
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            big.execute(ops_s)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / nS
+            ok_s = bool(((big.status_run if LOOP_IN_KERNEL else big.status).cpu().numpy() == 0).all())
+            ach = BYTES_PER_PAIR_F64 * Bs / (ms * 1e-3) / 1e9
+            streaming = {"batch": Bs, "steps": nS, "kernel_ms": ms, "pair_steps_per_s": Bs / (ms * 1e-3), "achieved": ach,
+                         "frac": ach / HBM_PEAK_GBS, "valid": ok_s,
+                         "note": "working set ~%d MB: streams from HBM (Infinity Cache 256 MiB)" % (Bs * 3450 // 1000000)}
+            del big
+
+        t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        return dict(B=B, elapsed=float(t_max.item()), kern_ms=kern_ms, kern_ms_eager=kern_ms_eager, ok=ok, graph=graph, n_ops=len(ops),
+                    sustained_steps=sustained_steps, streaming=streaming, wl=wl)
+
+    # the timed region(s): weak scaling keeps --batch instances per GPU, strong scaling shards --batch over the ranks
+    results = {}
+    for mode in modes:
+        results[mode] = measure(args.batch if mode == "weak" else args.batch // world)
+        if len(modes) > 1:
+            torch.cuda.empty_cache()
+    main_mode = modes[-1]                                    # (both measured: the strong-scaling figure is the line's `value`)
+    m = results[main_mode]
+    B, elapsed, kern_ms, kern_ms_eager, ok, graph, streaming, wl = (m["B"], m["elapsed"], m["kern_ms"], m["kern_ms_eager"], m["ok"],
+                                                                   m["graph"], m["streaming"], m["wl"])
+    ok = all(r["ok"] for r in results.values())
+    sustained_steps, n_ops = m["sustained_steps"], m["n_ops"]
 
     if rank == 0:
         total_pairs = float(B) * world * K
@@ -466,7 +642,8 @@ def main():
                 measured_cfg = (B == 65536 and args.lanes == 0 and args.mode == "pair" and not args.per_instance_noise
                                 and not args.restore_copy and not os.environ.get("DVI_ESKF_LIB")
                                 and LOOP_IN_KERNEL == LOOP_IN_KERNEL_DEFAULT and H == 16)
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch") if measured_cfg else None
+                tfj = json.load(open(tf))
+                traffic = tfj.get("hbm_bytes_per_step", tfj.get("hbm_bytes_per_launch")) if measured_cfg else None
             except Exception:
                 traffic = None
             if traffic is not None:
@@ -520,7 +697,7 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
+            "scaling": main_mode,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -538,7 +715,7 @@ def main():
                 "hip_graph": graph,
                 "time_loop": "in the kernel: a horizon is one dvi_eskf_run_epochs_from call = one launch of eskf_run_kernel" if LOOP_IN_KERNEL
                              else "on the host: one dvi_eskf_step call per step",
-                "timed_region": "every one of the %d steps is replayed from a HIP graph (%d graph launch%s)" % (K, len(ops), "" if len(ops) == 1 else "es")
+                "timed_region": "every one of the %d steps is replayed from a HIP graph (%d graph launch%s)" % (K, n_ops, "" if n_ops == 1 else "es")
                                 if graph else "steps launched from Python",
                 "untimed_preparation": "%d warm-up steps, graph capture and one launch of every captured graph, then %d replayed steps (%.2f s) to reach sustained clocks"
                                        % (W, sustained_steps, args.sustain_seconds),
@@ -552,6 +729,12 @@ def main():
                 "frac_wall": achieved_wall / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "traffic_over_algorithmic": (traffic / (BYTES_PER_PAIR_F64 * B)) if traffic else None,
+                # what actually crossed the fabric, against the same peak: `frac` prices the ALGORITHMIC bytes (a quarter of the
+                # covariances never leaves LDS between two steps of a run, so the fabric moves fewer)
+                "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "bound_note": "priced against HBM as SURVEY 8(d) defines the metric; by the counters of the committed profile neither pipe "
+                              "is saturated at this batch -- the fabric moves `traffic` at `frac_traffic` of peak, the vector ALUs are "
+                              "about 60 % issue-busy (profiles/*_sq_counters.txt): what the step lacks is overlap of the two",
                 "kernel": ("eskf_run_kernel: ONE launch per horizon (%d steps; the time loop, every step's pre phase and its "
                            "row-resident covariance rounds inside; between two steps of a launch the covariances of a quarter of "
                            "the instances stay in LDS); achieved = algorithmic bytes of a step / (launch duration / steps "
@@ -565,10 +748,25 @@ def main():
                 "copy_yardstick": yardstick,
             },
         }
+        if len(modes) > 1:      # N > 1 without --strong / --weak: the weak-scaling measurement of the same job, next to `value`
+            w_ = results["weak"]
+            out["weak"] = {"value": float(w_["B"]) * world * K / w_["elapsed"], "unit": "pair-steps/s", "scaling": "weak",
+                           "batch_per_gpu": w_["B"], "global_batch": w_["B"] * world, "ms_per_step": w_["elapsed"] / K * 1e3,
+                           "kernel_ms": w_["kern_ms"], "all_instances_ok": w_["ok"],
+                           "note": "the same timed region (barrier, EXACTLY K steps, final all-gather, MAX over ranks) with --batch instances "
+                                   "PER GPU; `value` of this line is the strong-scaling figure (--batch instances sharded over the ranks)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
             out["cpu_baseline_numpy"] = cpu_baseline_numpy(wl)
+            out["cpu_baseline_one_thread"] = cpu_baseline(wl, seconds_target=4.0, threads=1)
             out["parity"] = parity_check(wl)
+        del results, m, wl
+        torch.cuda.empty_cache()
+        if world == 1 and dist is None and not args.no_secondary and args.mode == "pair":
+            try:
+                out["secondary"] = secondary_block(dev, measure)
+            except Exception as ex:     # (never the reason a bench line is missing)
+                out["secondary"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -97,6 +97,9 @@ def lib() -> C.CDLL:
         # PyTorch must be loaded first: the library has to bind to the HIP runtime that
         # PyTorch ships, otherwise torch's streams / device pointers belong to another runtime
         import torch  # noqa: F401
+        if os.environ.get(LIB_OVERRIDE_ENV):
+            import sys
+            print(f"dvi_ekf_amd: {LIB_OVERRIDE_ENV} selects {path} instead of the package's own library", file=sys.stderr)
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the symbol is missing

@@ -680,9 +680,12 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
             if (hipStreamWaitEvent(h->side[s2], h->ev_fork, 0) != hipSuccess) rc_first = DVI_ESKF_EHIP;
             else forked[s2] = true;
         }
-        // (test hook, tests/test_gpu_capi.py: DVI_ESKF_TEST_FAIL_SPLIT_EPOCH=<e> makes the enqueue of epoch e fail)
+#ifdef ESKF_TEST_HOOKS      // (test build only, tests/test_gpu_capi.py: DVI_ESKF_TEST_FAIL_SPLIT_EPOCH=<e> makes the enqueue of epoch e fail)
         const char* fail_env = getenv("DVI_ESKF_TEST_FAIL_SPLIT_EPOCH");
         const int64_t fail_epoch = fail_env ? (int64_t)atoll(fail_env) : -1;
+#else
+        const int64_t fail_epoch = -1;
+#endif
         size_t off2 = 0;
         for (int64_t e = 0; e < sc->n_epochs && rc_first == DVI_ESKF_OK; ++e) {     // (enqueued epoch by epoch, alternating: both queues always have work)
             const int n = sc->n_pred[e];

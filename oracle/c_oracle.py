@@ -48,6 +48,8 @@ def lib(hp: bool = False):
         _lib.eskf_oracle_predict_batch.argtypes = [pp, C.c_int64, dp, dp, dp, dp, dp, dp, C.c_int, dp, dp]
         _lib.eskf_oracle_update_batch.argtypes = [pp, C.c_int64, dp, dp, dp, dp, dp, C.POINTER(C.c_int32)]
         _lib.eskf_oracle_num_threads.restype = C.c_int
+        _lib.eskf_oracle_set_num_threads.restype = C.c_int
+        _lib.eskf_oracle_set_num_threads.argtypes = [C.c_int]
     return _libs[hp]
 
 
@@ -121,3 +123,8 @@ class OracleBatch:
 
 def num_threads() -> int:
     return int(lib().eskf_oracle_num_threads())
+
+
+def set_num_threads(n: int) -> int:
+    """OpenMP threads of the batched drivers from now on; returns the number in effect."""
+    return int(lib().eskf_oracle_set_num_threads(int(n)))

@@ -623,3 +623,15 @@ int eskf_oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* threads the batched drivers use from now on (bench.py times the oracle on one thread as well as on all host cores);
+ * returns the number in effect */
+int eskf_oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n >= 1) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}

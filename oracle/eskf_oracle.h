@@ -61,6 +61,7 @@ void eskf_oracle_update_batch(const eskf_oracle_params* prm, int64_t B, double* 
                               const double* pos, const double* quat, const double* notch,
                               int32_t* status);
 int eskf_oracle_num_threads(void);
+int eskf_oracle_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

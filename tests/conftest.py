@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # an experiment build selected for the whole session would be tested instead of the product (tests that want another
+    # build select it for a child process of their own)
+    if os.environ.get("DVI_ESKF_LIB"):
+        raise pytest.UsageError("DVI_ESKF_LIB is set: the tests would not run against dvi_ekf_amd/libdvi_eskf.so")
 
 
 def _has_gpu() -> bool:

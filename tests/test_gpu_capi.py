@@ -271,56 +271,28 @@ def test_copy_state_is_a_bitwise_restore(dtype, B):
     assert L.dvi_eskf_copy_state(dst._h, None, None) == -1
 
 
-def test_run_epochs_error_after_the_fork_still_joins_the_side_streams(monkeypatch):
-    """An error while the two halves of an under-filled batch are being enqueued on the handle's side streams (here forced
-    by a test hook at epoch 2) must not leave those streams forked: eagerly the caller's stream has to wait for what was
-    already enqueued on them, and under capture an unjoined stream would make hipStreamEndCapture fail
-    (hipErrorStreamCaptureUnjoined) -- the call returns its error and the capture still ends."""
-    from tests.helpers import default_run
-    from dvi_ekf_amd.batch import BatchedESKF
-    from dvi_ekf_amd._capi import EskfError
-    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False)
-    B = 2176
-    f = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so, hold_frozen=False)
-    f.set_noise(Q, R)
-    f.set_state(x=np.tile(ri.x0, (B, 1)), P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
-    n_pred = np.array([4, 3, 5, 2], dtype=np.int32)
-    E, total = len(n_pred), int(n_pred.sum())
-    dev = f.device
-    t = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
-    args = (n_pred, t(ri.dt[:total]), t(ri.om[:total]), t(ri.acc[:total]), t(ri.pos[:E]), t(ri.quat[:E]), t(ri.notch[:E]))
-    f.reserve(int(n_pred.max()))
-    c = f.clone()
-    c.reserve(int(n_pred.max()))
-    ref = f.clone()
-    ref.run_epochs(*args)                                       # what an undisturbed run gives
-    monkeypatch.setenv("DVI_ESKF_TEST_FAIL_SPLIT_EPOCH", "2")
-    with pytest.raises(EskfError):
-        f.run_epochs(*args)
-    torch.cuda.synchronize(dev)                                 # (no fault, nothing left running unordered)
-    side = torch.cuda.Stream(device=dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    torch.cuda.synchronize(dev)
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr, stream=side):                     # capture_end() in __exit__ raises if a stream is left unjoined
-        with pytest.raises(EskfError):
-            c.run_epochs(*args)
-    torch.cuda.synchronize(dev)
-    monkeypatch.delenv("DVI_ESKF_TEST_FAIL_SPLIT_EPOCH")
-    # the handle is still usable: restored and run again it gives the undisturbed result
-    g = ref.clone()
-    h2 = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so, hold_frozen=False)
-    h2.set_noise(Q, R)
-    h2.set_state(x=np.tile(ri.x0, (B, 1)), P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
-    f.copy_state_from(h2)
-    f.run_epochs(*args)
-    sf, sg = f.get_state(), g.get_state()
-    for key in sf:
-        assert torch.equal(sf[key], sg[key]), key
+def test_run_epochs_error_after_the_fork_still_joins_the_side_streams(tmp_path):
+    """An error while the two halves of an under-filled batch are being enqueued on the handle's side streams must not leave
+    those streams forked: eagerly the caller's stream has to wait for what was already enqueued on them, and under capture an
+    unjoined stream would make hipStreamEndCapture fail (hipErrorStreamCaptureUnjoined) -- the call returns its error and the
+    capture still ends.  The failure is injected by a hook that only a TEST BUILD of the library contains
+    (-DESKF_TEST_HOOKS, built here into the test's temporary directory); the scenario runs in a child process with that
+    build selected (tests/_split_child.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = tmp_path / "libdvi_eskf_testhooks.so"
+    subprocess.check_call(["make", "-C", os.path.join(root, "dvi_ekf_amd", "csrc"), "-s", "-B", "EXTRA=-DESKF_TEST_HOOKS", f"OUT={lib}"], timeout=1200)
+    env = dict(os.environ)
+    env["DVI_ESKF_LIB"] = str(lib)
+    env.pop("DVI_ESKF_EPOCHS", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_split_child.py"), root], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "split child ok" in p.stdout
 
 
-@pytest.mark.parametrize("dtype,per_instance", [("float64", False), ("float64", True), ("float32", False)])
-def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance):
+@pytest.mark.parametrize("dtype,per_instance,B", [("float64", False, 2176), ("float64", True, 8320), ("float32", False, 8320), ("float64", False, 8320)])
+def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance, B):
     """An under-filled batch (B a multiple of 128, 2 048 <= B <= 16 384, every epoch with >= 2 predicts, no log rows):
     dvi_eskf_run_epochs runs the two halves of the batch on two streams of the handle's own -- one half's recurrences
     and Jacobian kernel next to the other half's covariance kernel.  Same bits as the epochs called one by one (which
@@ -328,7 +300,8 @@ def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance):
     from tests.helpers import default_run
     from dvi_ekf_amd.batch import BatchedESKF
     cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=False)
-    B = 2176                                                    # 17 x 128: halves of 1 088 = 17 groups of 64
+    # (B = 8 320 = 65 x 128: beyond what the long-horizon kernel takes in one generation of blocks -- the two streams; B = 2 176:
+    #  that kernel eagerly, the two streams under capture, where the ragged schedule cannot be uploaded)
     dt_ = getattr(torch, dtype)
     f = BatchedESKF(B, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so,
                     hold_frozen=False, dtype=dt_)
