@@ -513,7 +513,7 @@ def main():
                 n += 8 * H
             return n
 
-    def measure(B):
+    def measure(B, dump=True):
         """the contract's timed region for B instances on this rank: warm-up, EXACTLY K timed steps between barriers, MAX over ranks"""
         run = Run(B, rank * B)
         wl, f, status = run.wl, run.f, run.status
@@ -561,7 +561,7 @@ def main():
         graph = any(o[0] == "graph" for o in ops)
         kern_ms = ev_t[0].elapsed_time(ev_t[1]) / K
 
-        if args.dump_dofs and rank == 0:
+        if args.dump_dofs and rank == 0 and dump:
             allv = torch.cat(gathered, dim=0) if gathered is not None else dofs
             np.save(args.dump_dofs, allv.cpu().numpy())
 
@@ -764,7 +764,7 @@ def main():
         torch.cuda.empty_cache()
         if world == 1 and dist is None and not args.no_secondary and args.mode == "pair":
             try:
-                out["secondary"] = secondary_block(dev, measure)
+                out["secondary"] = secondary_block(dev, lambda b_: measure(b_, dump=False))
             except Exception as ex:     # (never the reason a bench line is missing)
                 out["secondary"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)

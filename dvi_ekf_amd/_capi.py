@@ -40,6 +40,7 @@ class Schedule(C.Structure):
         ("om", C.c_void_p), ("acc", C.c_void_p), ("imu_per_instance", C.c_int),
         ("pos", C.c_void_p), ("quat_xyzw", C.c_void_p), ("notch", C.c_void_p), ("meas_per_instance", C.c_int),
         ("status", C.c_void_p), ("t_log", C.POINTER(C.c_double)), ("rows_out", C.c_void_p),
+        ("t_pred", C.POINTER(C.c_double)), ("rows_pred_out", C.c_void_p), ("rows_instances", C.c_int64),
     ]
 
 

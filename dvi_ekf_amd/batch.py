@@ -269,7 +269,7 @@ class BatchedESKF:
         return status, K
 
     def run_epochs(self, n_pred, dt, om, acc, pos, quat, notch, t_log=None, src: Optional["BatchedESKF"] = None,
-                   status: Optional[torch.Tensor] = None):
+                   status: Optional[torch.Tensor] = None, t_pred=None, rows_instances: int = 0):
         """A whole run (Filter.run, Filter.py:144-168) enqueued by one call: epoch e = n_pred[e]
         predicts + the update with measurement e.  dt [total] | [total,B]; om/acc [total,3] |
         [total,B,3]; pos [E,3] | [E,B,3]; quat [E,4] | [E,B,4]; notch [E] | [E,B].
@@ -277,7 +277,10 @@ class BatchedESKF:
         after every update when their time stamps ``t_log`` [E] are given.  ``src``: the first epoch
         starts from that filter's state (dvi_eskf_run_epochs_from).  ``status``: a caller-owned [E,B]
         int32 tensor to write the status words into (none is allocated then).  Tensor arguments of the
-        filter's dtype on its device are used as they are."""
+        filter's dtype on its device are used as they are.
+        ``t_pred`` [total] instead of ``t_log``: the reference's own log -- one row per IMU sample (the propagated
+        state, Filter.py:230), the row of an epoch's last sample replaced by the state after the update
+        (Filter.py:393) -- for the first ``rows_instances`` instances (0 = all): rows [total,n,30]."""
         n_pred = np.ascontiguousarray(np.asarray(n_pred, dtype=np.int32))
         E, total = int(n_pred.shape[0]), int(n_pred.sum())
 
@@ -301,12 +304,20 @@ class BatchedESKF:
             status = torch.zeros((E, B), dtype=torch.int32, device=self.device)
         elif status.shape != (E, B) or status.dtype != torch.int32 or not status.is_contiguous():
             raise ValueError("status must be a contiguous int32 [E,B] tensor")
-        rows = tl = None
+        rows = tl = tpr = None
+        if t_log is not None and t_pred is not None:
+            raise ValueError("t_log (a row per update) and t_pred (a row per IMU sample) exclude each other")
         if t_log is not None:
             tl = np.ascontiguousarray(np.asarray(t_log, dtype=np.float64))
             if tl.shape != (E,):
                 raise ValueError("t_log must be [E]")
             rows = torch.empty((E, B, 30), dtype=self.dtype, device=self.device)
+        n_rows_inst = int(rows_instances) if 0 < int(rows_instances) < B else B
+        if t_pred is not None:
+            tpr = np.ascontiguousarray(np.asarray(t_pred, dtype=np.float64))
+            if tpr.shape != (total,):
+                raise ValueError("t_pred must be [sum(n_pred)]")
+            rows = torch.empty((total, n_rows_inst, 30), dtype=self.dtype, device=self.device)
         sc = _capi.Schedule()
         sc.n_epochs = E
         sc.n_pred = n_pred.ctypes.data_as(C.POINTER(C.c_int32))
@@ -315,7 +326,10 @@ class BatchedESKF:
         sc.pos, sc.quat_xyzw, sc.notch, sc.meas_per_instance = _ptr(tp), _ptr(tq), _ptr(tn), per
         sc.status = _ptr(status)
         sc.t_log = tl.ctypes.data_as(C.POINTER(C.c_double)) if tl is not None else None
-        sc.rows_out = _ptr(rows)
+        sc.rows_out = _ptr(rows) if tl is not None else None
+        sc.t_pred = tpr.ctypes.data_as(C.POINTER(C.c_double)) if tpr is not None else None
+        sc.rows_pred_out = _ptr(rows) if tpr is not None else None
+        sc.rows_instances = n_rows_inst if tpr is not None else 0
         if src is not None:
             _capi.check(self.lib.dvi_eskf_run_epochs_from(self._h, src._h, C.byref(sc), self._stream()), "dvi_eskf_run_epochs_from")
         else:

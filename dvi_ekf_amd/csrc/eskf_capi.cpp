@@ -55,6 +55,11 @@ struct dvi_eskf {
     int32_t* d_npred;
     int64_t npred_cap;
     std::vector<int32_t> npred_host;    // what d_npred holds (a run with the schedule of the run before uploads nothing)
+    // ... its state snapshots for the trajectory log ([rows][26][n_log]) and the rows' time stamps (device doubles)
+    void* d_xlog;
+    size_t xlog_bytes;
+    double* d_trows;
+    int64_t trows_cap;
 };
 
 namespace {
@@ -91,6 +96,10 @@ void free_buffers(dvi_eskf* h) {
     h->d_npred = nullptr;
     h->npred_cap = 0;
     h->npred_host.clear();
+    if (h->d_xlog) (void)hipFree(h->d_xlog);
+    if (h->d_trows) (void)hipFree(h->d_trows);
+    h->d_xlog = nullptr; h->xlog_bytes = 0;
+    h->d_trows = nullptr; h->trows_cap = 0;
     h->d_P = h->d_x = h->d_J = h->d_e = nullptr;
     h->d_status = nullptr;
     h->jcap = 0;
@@ -107,6 +116,8 @@ bool alloc_buffers(dvi_eskf* h) {
     h->d_npred = nullptr;
     h->npred_cap = 0;
     h->npred_host.clear();
+    h->d_xlog = nullptr; h->xlog_bytes = 0;
+    h->d_trows = nullptr; h->trows_cap = 0;
     if (hipMalloc(&h->d_aux, B * (eskf::AUX_WORDS0 + eskf::AUX_WORDSK) * es) != hipSuccess ||
         hipMalloc(&h->d_P, B * 300 * es) != hipSuccess || hipMalloc(&h->d_x, B * 36 * es) != hipSuccess ||
         hipMalloc(&h->d_J, B * eskf::JAC_WORDS * es) != hipSuccess ||
@@ -290,6 +301,8 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out) {
     h->d_noise = nullptr;             // (the struct copy aliased the source's buffers)
     h->d_npred = nullptr;
     h->npred_cap = 0;
+    h->d_xlog = nullptr; h->xlog_bytes = 0;
+    h->d_trows = nullptr; h->trows_cap = 0;
     h->side_ready = false;            // (... and its streams: the copy makes its own when it needs them)
     if (!alloc_buffers(h)) {
         delete h;
@@ -476,7 +489,7 @@ namespace {
 // block stepping its own instances.  Returns 1 if the run was enqueued that way, 0 if it has to go epoch by epoch
 // (log rows, other schedules, configurations the kernel does not cover, DVI_ESKF_RUN=0), < 0 on error.
 int run_pairs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream) {
-    if (sc->rows_out) return 0;
+    if (sc->rows_out || sc->rows_pred_out) return 0;
     if (sc->n_epochs > 0x7fffffffLL) return 0;
     for (int64_t e = 0; e < sc->n_epochs; ++e)
         if (sc->n_pred[e] != 1) return 0;
@@ -526,7 +539,6 @@ int run_pairs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule*
 // the kernel does not cover, a schedule that would have to be uploaded while the stream is being captured,
 // DVI_ESKF_EPOCHS=0), < 0 on error.
 int run_epochs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, void* stream) {
-    if (sc->rows_out) return 0;
     if (sc->n_epochs > 0x7fffffffLL) return 0;
     int64_t total = 0;
     bool uniform = true;
@@ -581,6 +593,36 @@ int run_epochs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule
         }
         ea.n_pred = h->d_npred;
     }
+    // the trajectory log: state snapshots written by the kernel, turned into rows afterwards (allocations and a copy from
+    // host memory: not while the stream is being captured)
+    const bool log_pred = sc->rows_pred_out != nullptr, log_epoch = sc->rows_out != nullptr;
+    const int64_t n_rows = log_pred ? total : log_epoch ? sc->n_epochs : 0;
+    const int64_t n_log = log_pred ? (sc->rows_instances > 0 && sc->rows_instances < h->B ? sc->rows_instances : h->B) : h->B;
+    if (n_rows > 0) {
+        if (capturing || h->captured) return 0;
+        const size_t need = (size_t)n_rows * 26 * (size_t)n_log * elem_size(h->dtype);
+        if (need > h->xlog_bytes || n_rows > h->trows_cap) {
+            if (hipDeviceSynchronize() != hipSuccess) return DVI_ESKF_EHIP;
+            if (need > h->xlog_bytes) {
+                if (h->d_xlog) (void)hipFree(h->d_xlog);
+                h->d_xlog = nullptr; h->xlog_bytes = 0;
+                if (hipMalloc(&h->d_xlog, need) != hipSuccess) { h->d_xlog = nullptr; return DVI_ESKF_ENOMEM; }
+                h->xlog_bytes = need;
+            }
+            if (n_rows > h->trows_cap) {
+                if (h->d_trows) (void)hipFree(h->d_trows);
+                h->d_trows = nullptr; h->trows_cap = 0;
+                if (hipMalloc((void**)&h->d_trows, (size_t)n_rows * sizeof(double)) != hipSuccess) { h->d_trows = nullptr; return DVI_ESKF_ENOMEM; }
+                h->trows_cap = n_rows;
+            }
+        }
+        if (hipMemcpyAsync(h->d_trows, log_pred ? sc->t_pred : sc->t_log, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            return DVI_ESKF_EHIP;
+        ea.xlog = h->d_xlog;
+        ea.xlog_mode = log_pred ? 1 : 2;
+        ea.n_log = n_log;
+    }
     if (capturing) h->captured = true;
     a.pending_hint = (h->maybe_pending || h->captured) ? 1 : 0;
     if (src) {
@@ -598,6 +640,11 @@ int run_epochs_in_one_launch(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule
     if (eskf::launch_epochs(h->dtype, h->lpi, ea, h->hp, s) != hipSuccess) return DVI_ESKF_EHIP;
     h->maybe_pending = true;        // the last epoch's update leaves its error state behind
     h->jac_ip = -1;
+    if (n_rows > 0) {               // the last row is the state after the run's last update: injected now, read from the state record
+        if (flush_pending(h, s) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+        if (eskf::launch_log_rows_run(h->dtype, n_rows, n_log, h->d_xlog, h->d_x, h->B, h->d_trows, log_pred ? sc->rows_pred_out : sc->rows_out, s) != hipSuccess)
+            return DVI_ESKF_EHIP;
+    }
     return 1;
 }
 
@@ -621,6 +668,7 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
     if (sc->n_epochs == 0) return DVI_ESKF_OK;
     if (!sc->n_pred || !sc->pos || !sc->quat_xyzw || !sc->notch) return DVI_ESKF_EINVAL;
     if (sc->rows_out && !sc->t_log) return DVI_ESKF_EINVAL;
+    if (sc->rows_pred_out && (!sc->t_pred || sc->rows_out || sc->rows_instances < 0 || sc->rows_instances > h->B)) return DVI_ESKF_EINVAL;
     int64_t total = 0;
     for (int64_t e = 0; e < sc->n_epochs; ++e) {
         if (sc->n_pred[e] < 0) return DVI_ESKF_EINVAL;
@@ -631,6 +679,36 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
     if (src && (src->B != h->B || src->dtype != h->dtype || src->device != h->device)) return DVI_ESKF_EINVAL;
     if (int one = run_pairs_in_one_launch(h, src, sc, stream)) return one < 0 ? one : DVI_ESKF_OK;
     if (int one = run_epochs_in_one_launch(h, src, sc, stream)) return one < 0 ? one : DVI_ESKF_OK;
+    if (sc->rows_pred_out) {
+        // a row per predict where the long-horizon kernel does not take the run: the reference's own call sequence, predict by
+        // predict (Filter.propagate + log row), then the update (which replaces the row of the epoch's last predict)
+        const size_t es_ = elem_size(h->dtype);
+        const size_t B_ = (size_t)h->B;
+        const size_t nl = (size_t)((sc->rows_instances > 0 && sc->rows_instances < h->B) ? sc->rows_instances : h->B);
+        if (nl != B_) return DVI_ESKF_EINVAL;      // (dvi_eskf_log_rows forms the rows of the whole batch: a subset needs the one-launch path)
+        const size_t dt_row_ = (sc->dt_per_instance ? B_ : 1) * es_, imu_row_ = (sc->imu_per_instance ? B_ : 1) * 3 * es_;
+        const size_t mrow_ = sc->meas_per_instance ? B_ : 1;
+        size_t g = 0;
+        for (int64_t e = 0; e < sc->n_epochs; ++e) {
+            for (int k = 0; k < sc->n_pred[e]; ++k, ++g) {
+                int rc = step_common(h, 1, 0, static_cast<const char*>(sc->dt) + g * dt_row_, sc->dt_per_instance, static_cast<const char*>(sc->om) + g * imu_row_,
+                                     static_cast<const char*>(sc->acc) + g * imu_row_, sc->imu_per_instance, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                                     stream, (e == 0 && k == 0) ? src : nullptr);
+                if (rc != DVI_ESKF_OK) return rc;
+                rc = dvi_eskf_log_rows(h, sc->t_pred[g], static_cast<char*>(sc->rows_pred_out) + g * B_ * 30 * es_, stream);
+                if (rc != DVI_ESKF_OK) return rc;
+            }
+            int rc = step_common(h, 0, 1, nullptr, 0, nullptr, nullptr, 0, static_cast<const char*>(sc->pos) + (size_t)e * mrow_ * 3 * es_,
+                                 static_cast<const char*>(sc->quat_xyzw) + (size_t)e * mrow_ * 4 * es_, static_cast<const char*>(sc->notch) + (size_t)e * mrow_ * es_,
+                                 sc->meas_per_instance, nullptr, sc->status ? sc->status + (size_t)e * B_ : nullptr, stream, (e == 0 && sc->n_pred[0] == 0) ? src : nullptr);
+            if (rc != DVI_ESKF_OK) return rc;
+            if (g > 0) {
+                rc = dvi_eskf_log_rows(h, sc->t_pred[g - 1], static_cast<char*>(sc->rows_pred_out) + (g - 1) * B_ * 30 * es_, stream);
+                if (rc != DVI_ESKF_OK) return rc;
+            }
+        }
+        return DVI_ESKF_OK;
+    }
     {   // size the Jacobian workspace for the longest epoch once, not epoch by epoch
         int longest = 0;
         for (int64_t e = 0; e < sc->n_epochs; ++e) longest = sc->n_pred[e] > longest ? sc->n_pred[e] : longest;

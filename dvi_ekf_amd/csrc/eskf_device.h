@@ -120,8 +120,12 @@ struct EpochsArgs {
     int32_t n_epochs;
     int32_t n_total;         // sum of n_pred
     int32_t n_uniform;
-    int32_t pad;
-    void* xlog;              // nullable [n_epochs][36][B]: the state record after every epoch's update, injected (log rows)
+    int32_t xlog_mode;       // 0: no log | 1: a state snapshot after every predict (row g of the run) | 2: after every epoch (row e)
+    void* xlog;              // [rows][26][n_log]: x26 of instances [0, n_log) -- after predict g the propagated state (Filter.py:230);
+                             // the snapshot an update belongs to (the epoch's last predict / the epoch) is overwritten with the
+                             // corrected state when the next epoch has injected it (Filter.py:393); the run's last one is left to the
+                             // caller (dvi_eskf_flush + the state record)
+    int64_t n_log;
     unsigned long long* stamps;   // diagnostic builds (ESKF_X_EPSTAMPS): [blocks][16 waves][8] cycle counters
 };
 // instances per block if the long-horizon kernel takes this run (shared noise model, default covariance kernel, no gain
@@ -143,6 +147,10 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
                       void* p_BW, void* R_WB, void* v_BW, const double* dofs6, const HostParams& hp, hipStream_t stream);
 
 hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream);
+// rows [n_rows][n_log][30] from the snapshots xlog [n_rows][26][n_log] of a run (EpochsArgs::xlog) -- the last row from the state
+// record xs [36][B] itself (flushed) -- with the time stamps t_rows (device, double [n_rows])
+hipError_t launch_log_rows_run(int dtype, int64_t n_rows, int64_t n_log, const void* xlog, const void* xs, int64_t B, const double* t_rows,
+                               void* rows, hipStream_t stream);
 
 // Filter.calculate_update_mse per instance: cam6 / imu6 host references (imu6 nullable), mse [B] device
 hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double* cam6, const double* imu6, void* mse,

@@ -269,6 +269,17 @@ __device__ __forceinline__ void role_ra(const EpochsArgs& A, const DevParams<T>&
 #pragma unroll
         for (int i = 0; i < 6; ++i) mb[MB_DOFS + i] = dofs[i];
         if (lane == 0) publish(flags + F_RA_CONST, e + 1);
+        // trajectory log: the snapshot the update before belongs to gets the corrected state (Filter.update overwrites the
+        // last row, Filter.py:393)
+        if (A.xlog_mode && live && b < A.n_log && e > 0 && (A.xlog_mode == 2 || g > 0)) {
+            T* xl = reinterpret_cast<T*>(A.xlog) + (int64_t)(A.xlog_mode == 2 ? e - 1 : g - 1) * 26 * A.n_log + b;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { xl[(0 + i) * A.n_log] = p[i]; xl[(3 + i) * A.n_log] = v[i]; xl[(19 + i) * A.n_log] = pc[i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xl[(6 + i) * A.n_log] = q[i];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xl[(10 + i) * A.n_log] = dofs[i];
+        }
         for (int k = 0; k < n; ++k, ++g) {
             T dt2, om2[3], acc2[3];                     // the next sample is on its way while this predict is computed
             load_sample(a, g + 1, g_end, b, dt2, om2, acc2);
@@ -308,6 +319,15 @@ __device__ __forceinline__ void role_ra(const EpochsArgs& A, const DevParams<T>&
             mat_to_quat(Rn, q);                                                     // state.py:67
 #pragma unroll
             for (int i = 0; i < 4; ++i) qo[i] = q[i];                               // = R_WB_old of the next predict (Filter.py:227)
+            if (A.xlog_mode == 1 && live && b < A.n_log) {                          // Filter.py:230: the propagated state
+                T* xl = reinterpret_cast<T*>(A.xlog) + (int64_t)g * 26 * A.n_log + b;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { xl[(0 + i) * A.n_log] = p[i]; xl[(3 + i) * A.n_log] = v[i]; xl[(19 + i) * A.n_log] = pc[i]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xl[(6 + i) * A.n_log] = q[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xl[(10 + i) * A.n_log] = dofs[i];
+            }
             dt = dt2;
 #pragma unroll
             for (int i = 0; i < 3; ++i) { om_n[i] = om2[i]; acc_n[i] = acc2[i]; }
@@ -396,6 +416,13 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
             for (int i = 0; i < 3; ++i) notch[i] += e1518[i];
             q3 += e11;
         }
+        if (A.xlog_mode && live && b < A.n_log && e > 0 && (A.xlog_mode == 2 || g > 0)) {      // (see role_ra)
+            T* xl = reinterpret_cast<T*>(A.xlog) + (int64_t)(A.xlog_mode == 2 ? e - 1 : g - 1) * 26 * A.n_log + b;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xl[(16 + i) * A.n_log] = notch[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xl[(22 + i) * A.n_log] = qc[i];
+        }
         EP_WAIT_BEGIN()
         wait_ge(flags + F_RA_CONST, e + 1);
         EP_WAIT_END(2)
@@ -450,6 +477,13 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
                 ax[AX_N0] = notch[0]; ax[AX_N1] = notch[1]; ax[AX_SP] = sp; ax[AX_CP] = cp;
             }
             if (lane == 0) publish(flags + F_RB, g + 1);
+            if (A.xlog_mode == 1 && live && b < A.n_log) {
+                T* xl = reinterpret_cast<T*>(A.xlog) + (int64_t)g * 26 * A.n_log + b;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xl[(16 + i) * A.n_log] = notch[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xl[(22 + i) * A.n_log] = qc[i];
+            }
 #pragma unroll
             for (int i = 0; i < 3; ++i) { om_o[i] = om_n[i]; om_n[i] = om2[i]; }
             dt = dt2;
@@ -1027,6 +1061,51 @@ static hipError_t launch_epochs_typed(int lpi, const EpochsArgs& ea, const DevPa
         default: return hipErrorInvalidValue;
     }
 }
+// The 30-column FilterTraj rows (FilterTraj.py:12-41) of a run from its state snapshots: row r of instance b from
+// xlog[r][26][n_log], the run's last row from the (flushed) state record xs[36][B]
+template <typename T>
+__global__ __launch_bounds__(256) void eskf_log_rows_run_kernel(int64_t n_rows, int64_t n_log, const T* xlog, const T* xs, int64_t B,
+                                                                const double* t_rows, T* rows) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n_rows * n_log) return;
+    const int64_t r = tid / n_log, b = tid - r * n_log;
+    const bool last = r + 1 == n_rows;
+    const T* src = last ? xs + b : xlog + r * 26 * n_log + b;
+    const int64_t st = last ? B : n_log;
+    auto X = [&](int w) { return src[(int64_t)w * st]; };
+    T q[4] = {X(6), X(7), X(8), X(9)}, qc[4] = {X(22), X(23), X(24), X(25)};
+    T* o = rows + tid * 30;
+    const T k = T(57.29577951308232087679815481410517);
+    T e[3];
+    o[0] = (T)t_rows[r];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[1 + i] = X(i); o[4 + i] = X(3 + i); o[20 + i] = X(19 + i); }
+    euler_xyz_deg(q, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[7 + i] = e[i];
+    o[10] = q[3]; o[11] = q[0]; o[12] = q[1]; o[13] = q[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { o[14 + i] = k * X(10 + i); o[17 + i] = X(13 + i); }
+    euler_xyz_deg(qc, e);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[23 + i] = e[i];
+    o[26] = qc[3]; o[27] = qc[0]; o[28] = qc[1]; o[29] = qc[2];
+}
+hipError_t launch_log_rows_run(int dtype, int64_t n_rows, int64_t n_log, const void* xlog, const void* xs, int64_t B, const double* t_rows,
+                               void* rows, hipStream_t stream) {
+    if (n_rows <= 0 || n_log <= 0) return hipSuccess;
+    const int64_t n = n_rows * n_log;
+    if ((n + 255) / 256 > 0x7fffffffLL) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(eskf_log_rows_run_kernel<double>, dim3(blocks), dim3(256), 0, stream, n_rows, n_log, (const double*)xlog, (const double*)xs, B,
+                           t_rows, (double*)rows);
+    else
+        hipLaunchKernelGGL(eskf_log_rows_run_kernel<float>, dim3(blocks), dim3(256), 0, stream, n_rows, n_log, (const float*)xlog, (const float*)xs, B,
+                           t_rows, (float*)rows);
+    return hipGetLastError();
+}
+
 hipError_t launch_epochs(int dtype, int lpi, const EpochsArgs& ea, const HostParams& hp, hipStream_t stream) {
     if (dtype == 0) return launch_epochs_typed<double>(lpi, ea, make_dev_params<double>(hp), stream);
     return launch_epochs_typed<float>(lpi, ea, make_dev_params<float>(hp), stream);

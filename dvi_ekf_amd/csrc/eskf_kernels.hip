@@ -1428,14 +1428,15 @@ constexpr int AUX0 = 12, AUXK = 8;
 template <typename T>
 __device__ __forceinline__ void advance_p_v_pc(T dt, const T (&acc_avg)[3], const T (&Rcr)[3], T (&p)[3], T (&v)[3], T (&pc)[3]) {
 #pragma clang fp contract(off)
+    // (the fusions of `p + dt * v + (dt * dt / 2) * a` etc. as the front end contracts these expressions where they are written
+    //  out -- pre4_body, predict_scalar --: a single predict gives the same bits through any of the pre kernels)
     const T h = dt * dt * T(0.5);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T vi = v[i];
-        const T dv = dt * vi;
-        p[i] = t_fma(h, acc_avg[i], p[i] + dv);                                 // equations.py:76
+        p[i] = t_fma(h, acc_avg[i], t_fma(dt, vi, p[i]));                       // equations.py:76
         v[i] = t_fma(dt, acc_avg[i], vi);                                       // equations.py:77
-        pc[i] = t_fma(dt, Rcr[i], pc[i] + dv);                                  // equations.py:83-85
+        pc[i] = t_fma(dt, Rcr[i], t_fma(dt, vi, pc[i]));                        // equations.py:83-85
     }
 }
 template <typename T, bool SIMU>

@@ -66,8 +66,13 @@ class Filter:
         self.H[6, 15] = 1
         # the kernels form the transition / noise Jacobians block-wise and never materialise them; the
         # reference's Fx / Fi attributes (Filter.py:259,265) are expanded on request from the blocks the
-        # last predict left in the workspace (dvi_eskf_get_jacobians)
-        self._dev.keep_jacobians(True)
+        # last predict left in the workspace (dvi_eskf_get_jacobians): ``propagate`` asks the device to keep
+        # them, ``run`` -- which enqueues whole runs -- only for the last frame's predicts
+        self._keeps_jacobians = False
+        # ``run`` enqueues all frames but the last as ONE device run (dvi_eskf_run_epochs) and steps through the
+        # last frame with the reference's own call sequence; False: every frame stepwise (one launch per call)
+        self.fast_run = True
+        self._log_dev: Optional[BatchedESKF] = None      # batch > 1: the filter that logs instance 0's trajectory
 
         self.traj = FilterTraj("kf")
         self.traj.append_row(self._log_row(self._config.min_t))
@@ -154,6 +159,8 @@ class Filter:
         for k, v in self.__dict__.items():
             if k == "_dev":
                 new._dev = self._dev.clone()
+            elif k == "_log_dev":
+                new._log_dev = None
             elif k in ("imu", "_probe", "_config"):
                 setattr(new, k, v)
             else:
@@ -187,14 +194,92 @@ class Filter:
 
     # -- main loop --------------------------------------------------------------------------
     def run(self, camera, k: int, run_desc_str: str) -> None:
-        """Filter.run (Filter.py:144-168): loop over camera frames 1.."""
+        """Filter.run (Filter.py:144-168): loop over camera frames 1..
+
+        All frames but the last are enqueued as ONE device run (``dvi_eskf_run_epochs``: the time loop and the predicts
+        of every frame inside the kernel); the trajectory log -- a row per IMU sample, the row of a frame's last sample
+        replaced by the corrected state -- comes back from the same run and ``traj`` is built once.  The last frame is
+        stepped through ``run_one_epoch`` as the reference does, so that ``Fx`` / ``Fi``, the gain returned by ``update``
+        and ``update_mse`` are those of the run's last predict / update."""
         old_t = self._config.min_t
         self.run_id = k
-        for i, t in enumerate(camera.t[1:]):
-            i_cam = i + 1
+        frames = list(enumerate(camera.t[1:], start=1))
+        if self.fast_run and len(frames) > 1:
+            old_t = self._run_frames_on_device(old_t, frames[:-1], camera)
+            frames = frames[-1:]
+        for i_cam, t in frames:
             self.run_one_epoch(old_t, t, i_cam, camera)
             self.calculate_update_mse(i_cam, camera)
             old_t = t
+
+    def _run_frames_on_device(self, old_t: float, frames, camera) -> float:
+        """``run_one_epoch`` for every frame of ``frames`` as one device run; returns the time of the last one."""
+        # host-side input preparation, sample by sample as propagate_imu does it (Filter.py:187-217): the synthetic IMU
+        # stream, the IMU reference trajectory, the camera measurements
+        real_probe_dofs = self._config.gt_joint_dofs
+        n_pred, t_pred, dts, oms, accs, pos, quat, notch = [], [], [], [], [], [], [], []
+        for i_cam, t in frames:
+            old_ti, n = old_t, 0
+            for cam_meas in self.imu.cam.samples_between(old_t, t):
+                real_probe_dofs[0][6] = cam_meas.notch
+                real_probe_dofs[1][6] = cam_meas.notch_d
+                real_probe_dofs[2][6] = cam_meas.notch_dd
+                om, acc = self.imu.eval_expr_single(cam_meas.t, *real_probe_dofs, cam_meas.acc, cam_meas.R, cam_meas.om,
+                                                    cam_meas.alp, overwrite=True)
+                if self.imu.ref is not None:
+                    self.imu.ref.append_value(cam_meas.t, cam_meas.vec, cam_meas.notch_arr)
+                self._dt = cam_meas.t - old_ti
+                dts.append(self._dt)
+                oms.append(np.asarray(om, dtype=float).reshape(3))
+                accs.append(np.asarray(acc, dtype=float).reshape(3))
+                t_pred.append(cam_meas.t)
+                old_ti = cam_meas.t
+                n += 1
+            n_pred.append(n)
+            cam = camera.traj.at_index(i_cam)
+            pos.append(np.asarray(cam.pos, dtype=float).reshape(3))
+            quat.append(np.asarray(cam.q.xyzw, dtype=float))
+            notch.append(float(camera.get_notch_vec_at(i_cam)[0]))
+            old_t = t
+        total = int(sum(n_pred))
+        args = (np.asarray(n_pred, dtype=np.int32), np.asarray(dts, dtype=float).reshape(total), np.asarray(oms, dtype=float).reshape(total, 3),
+                np.asarray(accs, dtype=float).reshape(total, 3), np.asarray(pos), np.asarray(quat), np.asarray(notch))
+        if self._keeps_jacobians:
+            self._dev.keep_jacobians(False)
+            self._keeps_jacobians = False
+        rows = None
+        if total > 0:
+            if self.batch == 1:
+                status, rows = self._dev.run_epochs(*args, t_pred=t_pred, rows_instances=1)
+            else:
+                # the trajectory log is instance 0's: a one-instance filter started from instance 0's state logs it (same
+                # inputs, same arithmetic), the batch itself runs without a log
+                logf = self._log_filter()
+                _, rows = logf.run_epochs(*args, t_pred=t_pred, rows_instances=1)
+                status, _ = self._dev.run_epochs(*args)
+        else:
+            status, _ = self._dev.run_epochs(*args)
+        st0 = status[:, 0].cpu().numpy()
+        for _ in range(int((st0 & 1).sum())):               # Filter.py:356-361: a message, nothing raised, the run goes on
+            print("ERROR: Singular matrix!")
+            print("Stopping simulation.")
+        self.status = status[-1].cpu().numpy()
+        self._propagated = False                            # (Fx / Fi: those of the next ``propagate``)
+        if rows is not None:
+            for row in rows[:, 0].cpu().numpy():
+                self.traj.append_row(row)
+        return old_t
+
+    def _log_filter(self) -> BatchedESKF:
+        """batch > 1: a one-instance filter holding instance 0's state (and the batch's noise model)."""
+        if self._log_dev is None:
+            self._log_dev = BatchedESKF(1, length=self._probe.scope_length, theta_cam=self._probe.theta_cam, frozen=self._frozen_dofs,
+                                        sigma_a=self.stdev_na, sigma_om=self.stdev_nom,
+                                        hold_frozen=bool(getattr(self._config, "golden_compat", False)), device=self._dev.device)
+        self._log_dev.set_noise(self.Q, self.R)
+        s = self._dev.get_state()
+        self._log_dev.set_state(x=s["x"][:1], P=s["P"][:1], om_old=s["om_old"][:1], acc_old=s["acc_old"][:1], q_old=s["q_old"][:1])
+        return self._log_dev
 
     def run_one_epoch(self, old_t: float, t: float, i_cam: int, camera) -> None:
         """>= 1 predictions then one update (Filter.py:170-185)."""
@@ -222,6 +307,9 @@ class Filter:
 
     def propagate(self, t, om, acc) -> None:
         """Filter.propagate (Filter.py:219-230) -- one kernel launch."""
+        if not self._keeps_jacobians:
+            self._dev.keep_jacobians(True)
+            self._keeps_jacobians = True
         self._dev.predict(self._dt, np.asarray(om, dtype=float), np.asarray(acc, dtype=float))
         self._propagated = True
         self.traj.append_row(self._log_row(t))

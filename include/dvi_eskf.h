@@ -187,6 +187,14 @@ typedef struct dvi_eskf_schedule {
     const double* t_log;    /* HOST  [n_epochs] time stamps of the log rows; needed with rows_out  */
     void* rows_out;         /* NULL or device [n_epochs,B,30]: dvi_eskf_log_rows after every update
                                (Filter.update appends to the trajectory log, Filter.py:394)       */
+    /* The reference's trajectory log has one row per IMU sample (Filter.propagate appends the propagated state,
+     * Filter.py:230) and Filter.update overwrites the last one with the corrected state (Filter.py:393, FilterTraj.py:66-69):
+     * rows_pred_out [total, rows_instances, 30] is exactly that log for the instances [0, rows_instances) of the batch
+     * (0 = all B; a driver that plots one trajectory asks for one), with the time stamps t_pred (HOST, [total]).  An epoch
+     * without a predict overwrites the row of the predict before it.  Exclusive with rows_out. */
+    const double* t_pred;
+    void* rows_pred_out;
+    int64_t rows_instances;
 } dvi_eskf_schedule;
 /* For an under-filled batch (2 048 <= B <= 16 384, B a multiple of 128, every epoch with at least two predicts, no
  * log rows, shared noise model, default covariance kernel) the two halves of the batch are enqueued on two streams

@@ -23,8 +23,10 @@ def same(a, b, what):
 def close(a, b, what, tol):
     for k in a:
         x, y = a[k].cpu().numpy().astype(np.float64), b[k].cpu().numpy().astype(np.float64)
-        s = max(1.0, float(np.abs(y).max()))
-        assert float(np.abs(x - y).max()) <= tol * s, (what, k, float(np.abs(x - y).max()), s)
+        assert np.array_equal(np.isfinite(x), np.isfinite(y)), (what, k, "non-finite entries differ")       # (the instance with the NaN measurement)
+        fin = np.isfinite(y)
+        s = max(1.0, float(np.abs(y[fin]).max()))
+        assert float(np.abs(x[fin] - y[fin]).max()) <= tol * s, (what, k, float(np.abs(x[fin] - y[fin]).max()), s)
 
 
 def main(B, dtype, n_pred, frozen, hold):
@@ -66,7 +68,9 @@ def main(B, dtype, n_pred, frozen, hold):
         assert int(ref_st[2, 3]) & 2
     exact = all(n >= 2 for n in n_pred)     # (epochs of one predict go through the four-chain pre kernel on path A: a different
                                             #  rounding sequence in the last bits, see tests/test_gpu_pre4.py)
-    cmp = same if exact else (lambda a, b, w: close(a, b, w, 1e-9 if dtype == torch.float64 else 2e-3))
+    # (an update that follows the one before after one predict or none meets an innovation covariance at the level of the
+    #  measurement noise, cond(S) ~ 1e6 and more: a last-bit difference of the nominal state in front of it comes out at 1e-8)
+    cmp = same if exact else (lambda a, b, w: close(a, b, w, 1e-6 if dtype == torch.float64 else 2e-2))
     # B: one launch
     g = snap.clone()
     st, rows = g.run_epochs(n_pred, dt, om, acc, pos, quat, notch)
@@ -105,6 +109,41 @@ def main(B, dtype, n_pred, frozen, hold):
         off += n
     g3.run_epochs(n_pred, dts, oms, accs, poss, quats, notchs)
     cmp(g3.get_state(), f3.get_state(), "shared streams")
+    # F: the trajectory log -- a row per IMU sample, the row of an epoch's last sample replaced by the corrected state -- from
+    # the run's own state snapshots
+    if total > 0:
+        t_pred = np.arange(total, dtype=np.float64) * 0.1 + 200.0
+        g4 = snap.clone()
+        nl = min(B, 3)
+        _, rows = g4.run_epochs(n_pred, dt, om, acc, pos, quat, notch, t_pred=t_pred, rows_instances=nl)
+        assert rows.shape == (total, nl, 30)
+        cmp(g4.get_state(), ref, "run with log rows")
+        # (i) the row an update belongs to is the log row of the state a run has when it ends with that update: the run cut after
+        #     every epoch in turn (a run gives the same bits wherever it is cut into calls)
+        cum = np.cumsum(n_pred)
+        for e in range(E):
+            if cum[e] == 0:
+                continue
+            gk = snap.clone()
+            o = int(cum[e])
+            gk.run_epochs(n_pred[:e + 1], dt[:o], om[:o], acc[:o], pos[:e + 1], quat[:e + 1], notch[:e + 1])
+            want = gk.log_rows(float(t_pred[o - 1]))[:nl]
+            if e + 1 < E and n_pred[e + 1] == 0:
+                continue                            # (the next epoch has no sample of its own: its update replaces this row once more)
+            assert torch.equal(rows[o - 1], want) or bool(torch.isnan(want).any()), ("row of update", e)
+        # (ii) the rows of the samples in between (propagated states) against the reference's call sequence (predict, log row, ...,
+        #      update, log row) on a handle that keeps its Jacobians and therefore never takes the one-launch path: another
+        #      rounding sequence (P is symmetrised after every predict there), compared where the schedule leaves that benign
+        if exact:
+            f4 = snap.clone()
+            f4.keep_jacobians(True)
+            _, rows_ref = f4.run_epochs(n_pred, dt, om, acc, pos, quat, notch, t_pred=t_pred)
+            assert rows_ref.shape == (total, B, 30)
+            r, rr = rows.cpu().numpy().astype(np.float64), rows_ref[:, :nl].cpu().numpy().astype(np.float64)
+            assert np.array_equal(r[:, :, 0], rr[:, :, 0])
+            fin = np.isfinite(rr) & np.isfinite(r)
+            tol = 1e-6 if dtype == torch.float64 else 2e-2
+            assert np.abs(r[fin] - rr[fin]).max() <= tol * max(1.0, np.abs(rr[fin]).max()), float(np.abs(r[fin] - rr[fin]).max())
     print("epochs child ok", B, dtype, n_pred)
 
 

@@ -29,7 +29,7 @@ def _free_port():
 def _bench(tmp_path, nranks, name, backend="gloo", force_dist=False, self_launch=False):
     out = tmp_path / f"{name}.npy"
     args = ["--gpus", str(nranks), "--steps", "24", "--warmup", "0", "--batch", "2048", "--strong", "--horizon", "8",
-            "--no-cpu-baseline", "--dump-dofs", str(out)]
+            "--no-cpu-baseline", "--no-secondary", "--dump-dofs", str(out)]
     env = dict(os.environ, DVI_BENCH_BACKEND=backend, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     if force_dist:
         env["DVI_BENCH_FORCE_DIST"] = "1"

@@ -52,4 +52,6 @@ def test_frozen_dofs_zeroed_by_every_predict():
 def test_epochs_of_one_and_of_no_predict_in_the_schedule():
     """epochs with a single predict take the four-chain pre kernel on the epoch-by-epoch side (a different rounding
     sequence in the last bits): closeness instead of equality; an epoch without a predict is an update on its own"""
-    _child(300, "f64", "3,1,0,4,1")
+    # (frozen extrinsics: the unfrozen Monte-Carlo instances amplify a last-bit difference by orders of magnitude within a few
+    #  updates, DESIGN.md section 5 -- a closeness bound says nothing there)
+    _child(300, "f64", "3,1,0,4,1", frozen="111111")

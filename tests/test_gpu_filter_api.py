@@ -131,3 +131,60 @@ def test_update_mse_is_a_device_reduction_and_filter_exposes_fx_fi(tmp_path):
     kf._config.interframe_vals = 10
     m = kf.calculate_metric(3, cam)
     assert np.isfinite(m) and m >= kf.calculate_dof_metric()
+
+
+def test_run_enqueued_as_one_device_run_equals_the_stepwise_run(tmp_path):
+    """Filter.run enqueues all frames but the last as ONE device run (dvi_eskf_run_epochs with a log row per IMU sample)
+    and steps through the last frame; with ``fast_run = False`` it is the reference's call sequence, one launch per call.
+    Same trajectory log (row count, time stamps, values), same final state, Fx / Fi / update_mse of the last frame."""
+    from dvi_ekf_amd import Simulator
+    for golden_compat, n_rows in ((True, 10), (False, 91)):
+        sims = []
+        for fast in (True, False):
+            sim = Simulator(_config(tmp_path / f"{golden_compat}_{fast}", golden_compat))
+            sim.kf.fast_run = fast
+            sim.run_once()
+            sims.append(sim)
+        a, b = sims[0].kf, sims[1].kf
+        ra, rb = a.traj.as_array(), b.traj.as_array()
+        assert ra.shape == rb.shape == (n_rows, 30)
+        assert np.array_equal(ra[:, 0], rb[:, 0])                               # time stamps
+        assert np.abs(ra - rb).max() <= 1e-11 * max(1.0, np.abs(rb).max())
+        assert np.abs(a._states.vector - b._states.vector).max() <= 1e-11
+        assert np.abs(a._P - b._P).max() <= 1e-11 * np.abs(b._P).max()
+        assert a.Fx is not None and np.abs(a.Fx - b.Fx).max() <= 1e-11 and np.abs(a.Fi - b.Fi).max() <= 1e-11
+        assert a.update_mse == pytest.approx(b.update_mse, rel=1e-9)
+        assert np.array_equal(a.imu.ref.as_array() if hasattr(a.imu.ref, "as_array") else np.asarray(a.imu.ref.t),
+                              b.imu.ref.as_array() if hasattr(b.imu.ref, "as_array") else np.asarray(b.imu.ref.t))
+
+
+def test_batched_run_logs_instance_zero(tmp_path):
+    """config.batch > 1: the batch runs without a log, a one-instance filter started from instance 0's state logs the
+    trajectory -- the same rows as the single-instance run, and every instance ends where instance 0 ends."""
+    from dvi_ekf_amd import Simulator
+    one = Simulator(_config(tmp_path / "one", False))
+    one.run_once()
+    many = Simulator(_config(tmp_path / "many", False, batch=257))
+    many.run_once()
+    ra, rb = one.kf.traj.as_array(), many.kf.traj.as_array()
+    assert ra.shape == rb.shape == (91, 30)
+    assert np.abs(ra - rb).max() <= 1e-11 * max(1.0, np.abs(ra).max())
+    sb = many.kf.states_batch
+    assert sb.shape == (257, 26) and np.array_equal(sb[0], sb[-1])
+    assert np.abs(sb[0] - one.kf._states.vector).max() <= 1e-11
+
+
+def test_the_reference_s_entry_script_runs_under_its_own_package_name(tmp_path, monkeypatch):
+    """The statements of the reference's main.py -- ``from dvi_ekf import Config, Simulator``; ``Config("config.yaml")``;
+    ``Simulator(config)``; ``run_once()``; ``plot(compact=True)`` -- in a directory that holds the reference's config.yaml and
+    data: the alias package resolves to this build and the default run comes out (v1 plumbing: 91 log rows)."""
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(GOLDEN, "data"), work / "data")
+    shutil.copy(os.path.join(GOLDEN, "config.yaml"), work / "config.yaml")
+    monkeypatch.chdir(work)
+    from dvi_ekf import Config, Simulator
+    config = Config("config.yaml")
+    sim = Simulator(config)
+    sim.run_once()
+    sim.plot(compact=True)
+    assert sim.kf.traj.num_values == 91 and np.isfinite(sim.kf.traj.as_array()).all()
