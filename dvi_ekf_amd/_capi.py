@@ -53,6 +53,7 @@ SIGNATURES = {
     "dvi_eskf_create": (_i, [C.POINTER(Params), _i64, _i, _i, _hpp]),
     "dvi_eskf_clone": (_i, [_vp, _vp, _hpp]),
     "dvi_eskf_copy_state": (_i, [_vp, _vp, _vp]),
+    "dvi_eskf_copy_instances": (_i, [_vp, _vp, _i64, _vp]),
     "dvi_eskf_destroy": (None, [_vp]),
     "dvi_eskf_batch": (_i64, [_vp]),
     "dvi_eskf_dtype": (_i, [_vp]),

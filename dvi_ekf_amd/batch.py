@@ -74,6 +74,10 @@ class BatchedESKF:
         """Device-to-device restore of x, P and the buffers from another handle."""
         _capi.check(self.lib.dvi_eskf_copy_state(self._h, other._h, self._stream()), "dvi_eskf_copy_state")
 
+    def copy_instances_from(self, other: "BatchedESKF", first: int = 0) -> None:
+        """This filter's instances <- instances [first, first + self.batch) of ``other`` (device-to-device)."""
+        _capi.check(self.lib.dvi_eskf_copy_instances(self._h, other._h, int(first), self._stream()), "dvi_eskf_copy_instances")
+
     # -- helpers ---------------------------------------------------------------------
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

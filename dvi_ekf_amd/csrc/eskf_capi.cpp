@@ -349,6 +349,21 @@ int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream) {
     return DVI_ESKF_OK;
 }
 
+int dvi_eskf_copy_instances(dvi_eskf* dst, const dvi_eskf* src, int64_t first, void* stream) {
+    if (!dst || !src || dst == src || dst->dtype != src->dtype || dst->device != src->device) return DVI_ESKF_EINVAL;
+    if (first < 0 || first + dst->B > src->B) return DVI_ESKF_EINVAL;
+    DeviceGuard g(src->device);
+    if (!g.ok) return DVI_ESKF_EHIP;
+    hipStream_t s = (hipStream_t)stream;
+    if (flush_pending(const_cast<dvi_eskf*>(src), s) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+    if (stream_is_capturing(s)) dst->captured = true;
+    // whatever was due on dst is overwritten together with the state it belonged to
+    if ((dst->maybe_pending || dst->captured) && hipMemsetAsync(dst->d_status, 0, (size_t)dst->B * sizeof(int32_t), s) != hipSuccess) return DVI_ESKF_EHIP;
+    dst->maybe_pending = false;
+    if (eskf::launch_copy_instances(src->dtype, src->d_P, src->d_x, src->B, first, dst->d_P, dst->d_x, dst->B, s) != hipSuccess) return DVI_ESKF_EHIP;
+    return DVI_ESKF_OK;
+}
+
 void dvi_eskf_destroy(dvi_eskf* h) {
     if (!h) return;
     DeviceGuard g(h->device);

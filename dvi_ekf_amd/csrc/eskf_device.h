@@ -136,6 +136,8 @@ hipError_t launch_epochs(int dtype, int lpi, const EpochsArgs& ea, const HostPar
 hipError_t launch_step(int dtype, int lpi, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 hipError_t launch_flush(int dtype, const StepArgs& a, const HostParams& hp, hipStream_t stream);
 bool epoch_sub_batches_ok(int lpi, int64_t sub_first, int64_t sub_count, int n_pred, bool per_instance_noise, bool gain_out, bool have_aux);
+hipError_t launch_copy_instances(int dtype, const void* srcP, const void* srcx, int64_t srcB, int64_t first, void* dstP, void* dstx, int64_t dstB,
+                                 hipStream_t stream);
 hipError_t launch_copy_state(const void* srcP, void* dstP, size_t bytesP, const void* srcx, void* dstx, size_t bytesx, hipStream_t stream);
 hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
                        const void* qo4, void* xs, void* Ppk, hipStream_t stream);

@@ -4481,6 +4481,31 @@ hipError_t launch_copy_state(const void* srcP, void* dstP, size_t bytesP, const 
     return hipGetLastError();
 }
 
+// the records of the instances [first, first + dstB) of one handle into another (dvi_eskf_copy_instances)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_instances_kernel(const T* __restrict__ sP, const T* __restrict__ sx, int64_t sB, int64_t first,
+                                                             T* __restrict__ dP, T* __restrict__ dx, int64_t dB) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dB * 300; i += stride) dP[i] = sP[first * 300 + i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < dB * 36; i += stride) {
+        const int64_t w = i / dB, b = i - w * dB;
+        dx[w * dB + b] = sx[w * sB + first + b];
+    }
+}
+hipError_t launch_copy_instances(int dtype, const void* srcP, const void* srcx, int64_t srcB, int64_t first, void* dstP, void* dstx, int64_t dstB,
+                                 hipStream_t stream) {
+    if (dstB <= 0) return hipSuccess;
+    int64_t blocks = (dstB * 300 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == 0)
+        hipLaunchKernelGGL(copy_instances_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)srcP, (const double*)srcx, srcB, first,
+                           (double*)dstP, (double*)dstx, dstB);
+    else
+        hipLaunchKernelGGL(copy_instances_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)srcP, (const float*)srcx, srcB, first,
+                           (float*)dstP, (float*)dstx, dstB);
+    return hipGetLastError();
+}
+
 hipError_t launch_pack(int dtype, int64_t B, const void* x26, const void* P576, const void* om3, const void* acc3,
                        const void* qo4, void* xs, void* Ppk, hipStream_t stream) {
     const int threads = 256;

@@ -216,6 +216,8 @@ class Filter:
         """``run_one_epoch`` for every frame of ``frames`` as one device run; returns the time of the last one."""
         # host-side input preparation, sample by sample as propagate_imu does it (Filter.py:187-217): the synthetic IMU
         # stream, the IMU reference trajectory, the camera measurements
+        import time
+        t_host0 = time.perf_counter()
         real_probe_dofs = self._config.gt_joint_dofs
         n_pred, t_pred, dts, oms, accs, pos, quat, notch = [], [], [], [], [], [], [], []
         for i_cam, t in frames:
@@ -248,6 +250,8 @@ class Filter:
             self._dev.keep_jacobians(False)
             self._keeps_jacobians = False
         rows = None
+        torch.cuda.synchronize(self._dev.device)
+        t_dev0 = time.perf_counter()
         if total > 0:
             if self.batch == 1:
                 status, rows = self._dev.run_epochs(*args, t_pred=t_pred, rows_instances=1)
@@ -259,7 +263,11 @@ class Filter:
                 status, _ = self._dev.run_epochs(*args)
         else:
             status, _ = self._dev.run_epochs(*args)
-        st0 = status[:, 0].cpu().numpy()
+        st0 = status[:, 0].cpu().numpy()                     # (synchronises: the run is through)
+        # where the wall time of this call went: the reference's sample-by-sample input synthesis on the host against the
+        # filter run itself on the device
+        self.last_run_timing = {"host_input_preparation_s": t_dev0 - t_host0, "device_run_s": time.perf_counter() - t_dev0,
+                                "frames": len(frames), "imu_samples": total}
         for _ in range(int((st0 & 1).sum())):               # Filter.py:356-361: a message, nothing raised, the run goes on
             print("ERROR: Singular matrix!")
             print("Stopping simulation.")
@@ -277,8 +285,7 @@ class Filter:
                                         sigma_a=self.stdev_na, sigma_om=self.stdev_nom,
                                         hold_frozen=bool(getattr(self._config, "golden_compat", False)), device=self._dev.device)
         self._log_dev.set_noise(self.Q, self.R)
-        s = self._dev.get_state()
-        self._log_dev.set_state(x=s["x"][:1], P=s["P"][:1], om_old=s["om_old"][:1], acc_old=s["acc_old"][:1], q_old=s["q_old"][:1])
+        self._log_dev.copy_instances_from(self._dev, 0)
         return self._log_dev
 
     def run_one_epoch(self, old_t: float, t: float, i_cam: int, camera) -> None:

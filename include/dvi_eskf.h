@@ -101,6 +101,12 @@ int dvi_eskf_clone(const dvi_eskf* src, void* stream, dvi_eskf** out);
  * Simulator.reset_kf (Simulator.py:160-161) when the initial state is kept on the device. */
 int dvi_eskf_copy_state(dvi_eskf* dst, const dvi_eskf* src, void* stream);
 
+/* dst <- the instances [first, first + dvi_eskf_batch(dst)) of src (device-to-device; same dtype and device; a pending
+ * injection of src is applied first, one of dst is dropped).  How a driver that logs or plots ONE trajectory of a batch
+ * (the reference-shaped Filter with config.batch > 1) starts a one-instance filter from instance 0's state without
+ * unpacking the batch. */
+int dvi_eskf_copy_instances(dvi_eskf* dst, const dvi_eskf* src, int64_t first, void* stream);
+
 void dvi_eskf_destroy(dvi_eskf* h);
 
 int64_t dvi_eskf_batch(const dvi_eskf* h);

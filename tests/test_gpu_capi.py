@@ -356,3 +356,28 @@ def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance, B)
     sc_ = c.get_state()
     for key in sf:
         assert torch.equal(sf[key], sc_[key]), ("captured", key)
+
+
+def test_copy_instances_takes_a_slice_of_another_batch():
+    """dvi_eskf_copy_instances: a small filter <- instances [first, first + b) of a large one, incl. a pending injection of
+    the source; bad ranges are refused."""
+    from tests.helpers import default_run
+    from dvi_ekf_amd.batch import BatchedESKF
+    from dvi_ekf_amd import _capi
+    cfg, ri, Q, R, sa, so = default_run(golden_compat=True, fast=True)
+    mk = lambda b: BatchedESKF(b, length=cfg.model.length, theta_cam=cfg.model.angle, frozen=[0] * 6, sigma_a=sa, sigma_om=so, hold_frozen=True)
+    big, small = mk(77), mk(5)
+    rng = np.random.default_rng(3)
+    x0 = np.tile(ri.x0, (77, 1))
+    x0[:, 10:16] += rng.normal(0, 0.01, (77, 6))
+    big.set_noise(Q, R)
+    big.set_state(x=x0, P=ri.P0, om_old=ri.om0, acc_old=ri.acc0)
+    big.step(ri.dt[0], ri.om[0], ri.acc[0], ri.pos[0], ri.quat[0], ri.notch[0])      # (leaves an injection pending)
+    small.copy_instances_from(big, 40)
+    a, b = big.get_state(), small.get_state()
+    for k in a:
+        assert torch.equal(a[k][40:45], b[k]), k
+    L = _capi.lib()
+    assert L.dvi_eskf_copy_instances(small._h, big._h, 73, None) == -1        # 73 + 5 > 77
+    assert L.dvi_eskf_copy_instances(small._h, big._h, -1, None) == -1
+    assert L.dvi_eskf_copy_instances(small._h, small._h, 0, None) == -1
