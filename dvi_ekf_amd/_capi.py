@@ -21,6 +21,7 @@ def lib_path() -> str:
     return os.environ.get(LIB_OVERRIDE_ENV) or LIB_PATH
 
 F64, F32 = 0, 1
+FIX_Q1, FIX_Q3, FIX_Q6, FIX_Q9 = 1, 2, 4, 8      # dvi_eskf_params.quirks_fixed
 STATUS_SINGULAR, STATUS_NONFINITE = 1, 2
 
 
@@ -28,7 +29,7 @@ class Params(C.Structure):
     """dvi_eskf_params"""
     _fields_ = [
         ("L", C.c_double), ("theta_cam", C.c_double), ("frozen", C.c_int32 * 6), ("hold_frozen", C.c_int32),
-        ("sigma_a", C.c_double * 3), ("sigma_om", C.c_double * 3),
+        ("sigma_a", C.c_double * 3), ("sigma_om", C.c_double * 3), ("quirks_fixed", C.c_int32),
     ]
 
 

@@ -23,7 +23,7 @@ def _ptr(t: Optional[torch.Tensor]):
 class BatchedESKF:
     def __init__(self, batch: int, *, length: float, theta_cam: float, frozen: Sequence[int],
                  sigma_a, sigma_om, hold_frozen: bool = False, dtype: torch.dtype = torch.float64,
-                 device: Optional[torch.device] = None, _handle=None):
+                 device: Optional[torch.device] = None, _handle=None, quirks_fixed: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedESKF needs a HIP device: the filter arithmetic only exists as HIP kernels")
         self.lib = _capi.lib()
@@ -36,7 +36,7 @@ class BatchedESKF:
         self.batch = int(batch)
         self._prm = dict(length=float(length), theta_cam=float(theta_cam), frozen=[int(bool(f)) for f in frozen],
                          sigma_a=[float(v) for v in sigma_a], sigma_om=[float(v) for v in sigma_om],
-                         hold_frozen=bool(hold_frozen))
+                         hold_frozen=bool(hold_frozen), quirks_fixed=int(quirks_fixed))
         self.Q = np.eye(13)
         self.R = np.eye(7)
         if _handle is not None:
@@ -47,6 +47,7 @@ class BatchedESKF:
         p.frozen[:] = self._prm["frozen"]
         p.sigma_a[:] = self._prm["sigma_a"]
         p.sigma_om[:] = self._prm["sigma_om"]
+        p.quirks_fixed = self._prm["quirks_fixed"]      # _capi.FIX_Q1 | FIX_Q3 | FIX_Q6 | FIX_Q9 (include/dvi_eskf.h); 0 = the v1 source
         h = C.c_void_p()
         _capi.check(self.lib.dvi_eskf_create(C.byref(p), self.batch, _capi.F64 if dtype == torch.float64 else _capi.F32,
                                              self.device.index or 0, C.byref(h)), "dvi_eskf_create")

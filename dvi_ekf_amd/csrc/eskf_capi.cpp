@@ -214,6 +214,12 @@ int step_common(dvi_eskf* h, int n_pred, int do_update, const void* dt, int dt_p
     if (n_pred > 0 && (!dt || !om || !acc)) return DVI_ESKF_EINVAL;
     if (do_update && (!pos || !quat || !notch)) return DVI_ESKF_EINVAL;
     if (n_pred == 0 && !do_update) return DVI_ESKF_OK;
+    // quirk Q1 switched off (dvi_eskf_params.quirks_fixed): predicts only through the covariance kernel that knows the other
+    // column layout of the camera rows -- row-resident, 32 lanes per instance, shared noise model, no gyro block in Q, no gain output
+    if (!(h->hp.quirks & eskf::QK_Q1) && n_pred > 0) {
+        const bool q_gyro = h->hp.qd[3] != 0.0 || h->hp.qd[4] != 0.0 || h->hp.qd[5] != 0.0 || h->hp.q_gyro_any;
+        if (h->lpi != 1 || h->d_noise || q_gyro || (do_update && K_out)) return DVI_ESKF_EINVAL;
+    }
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
     if (int rc = ensure_jcap(h, n_pred, (hipStream_t)stream)) return rc;
@@ -267,6 +273,9 @@ int dvi_eskf_create(const dvi_eskf_params* p, int64_t batch, int dtype, int devi
     h->hp.frozen_mask = 0;
     for (int i = 0; i < 6; ++i) if (p->frozen[i]) h->hp.frozen_mask |= (1 << i);
     h->hp.hold_frozen = p->hold_frozen ? 1 : 0;
+    if (p->quirks_fixed & ~(DVI_ESKF_FIX_Q1 | DVI_ESKF_FIX_Q3 | DVI_ESKF_FIX_Q6 | DVI_ESKF_FIX_Q9)) { delete h; return DVI_ESKF_EINVAL; }
+    h->hp.quirks = eskf::QK_V1 & ~((p->quirks_fixed & DVI_ESKF_FIX_Q1 ? eskf::QK_Q1 : 0) | (p->quirks_fixed & DVI_ESKF_FIX_Q3 ? eskf::QK_Q3 : 0) |
+                                   (p->quirks_fixed & DVI_ESKF_FIX_Q6 ? eskf::QK_Q6 : 0) | (p->quirks_fixed & DVI_ESKF_FIX_Q9 ? eskf::QK_Q9 : 0));
     for (int i = 0; i < 3; ++i) { h->hp.sig_a[i] = p->sigma_a[i]; h->hp.sig_om[i] = p->sigma_om[i]; }
     for (int i = 0; i < 13; ++i) h->hp.qd[i] = 1.0;   // Q = eye before set_noise (Filter.py:68)
     for (int i = 0; i < 7; ++i) h->hp.r[i] = 1.0;
@@ -882,7 +891,7 @@ int dvi_eskf_get_jacobians(const dvi_eskf* h, void* Fx_out, void* Fi_out, void* 
     if (h->jac_ip < 0) return DVI_ESKF_EINVAL;     // no predict since dvi_eskf_keep_jacobians(h, 1)
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
-    hipError_t e = eskf::launch_jacobians(h->dtype, h->B, h->d_J, h->jac_ip, Fx_out, Fi_out, (hipStream_t)stream);
+    hipError_t e = eskf::launch_jacobians(h->dtype, h->B, h->d_J, h->jac_ip, Fx_out, Fi_out, h->hp.quirks, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
 
@@ -936,6 +945,7 @@ int dvi_eskf_imu_synthesize(const dvi_eskf_params* p, int dtype, int device, int
     if (!g.ok) return DVI_ESKF_EHIP;
     eskf::HostParams hp{};
     hp.L = p->L; hp.theta_cam = p->theta_cam;
+    hp.quirks = eskf::QK_V1;
     hipError_t e = eskf::launch_imu(dtype, n, R_WC, om_CW, acc_CW, alp_CW, notch, notch_per_sample ? 1 : 0, p_CW, v_CW,
                                     om_B, acc_B, p_BW, R_WB, v_BW, dofs6, hp, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;

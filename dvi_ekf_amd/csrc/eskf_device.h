@@ -13,6 +13,10 @@ constexpr int DVI_STATUS_NONFINITE = 2;
 constexpr int DVI_STATUS_PENDING = 1 << 30;   // workspace word only: the update's error state is not injected yet
 constexpr int JAC_WORDS = 96;  // words per Jacobian record (eskf_kernels.hip: JW)
 constexpr int AUX_WORDS0 = 12, AUX_WORDSK = 8;   // eskf_kernels.hip: AUX0, AUXK
+// The quirks of the v1 source that can be switched off on the device (include/dvi_eskf.h): bit set = the v1
+// behaviour is in force.  Q3 / Q6 / Q9 are wave-uniform branches of the lane-per-instance chains; Q1 changes where the camera
+// rows of Fx take their operands and is a template parameter of the covariance kernels that serve it.
+constexpr int QK_Q1 = 1, QK_Q3 = 2, QK_Q6 = 4, QK_Q9 = 8, QK_V1 = 15;
 constexpr int NOISE_WORDS = 24; // per-instance noise record: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad   // words per Jacobian record (eskf_kernels.hip: JW)
 
 // constants of one filter configuration, in the kernel's working precision; passed by value
@@ -28,6 +32,7 @@ struct DevParams {
     int q_gyro;         // diag(Q)[3:6] has a non-zero entry
     int jfull;          // the pre kernels write all 85 block words of a record (with the N6 block): q_gyro, or the
                         // handle keeps the Jacobians for dvi_eskf_get_jacobians
+    int quirks;         // QK_* bits: which of the switchable v1 quirks are in force (QK_V1 = all: the reference as it is)
 };
 
 struct HostParams {
@@ -37,6 +42,7 @@ struct HostParams {
     int frozen_mask, hold_frozen;
     int q_gyro_any;     // per-instance noise: some instance has a non-zero gyro block in Q
     int keep_jac;       // dvi_eskf_keep_jacobians: full Jacobian records although Q has no gyro block
+    int quirks;         // QK_* bits in force (QK_V1 unless dvi_eskf_params.quirks_fixed switches some off)
 };
 
 template <typename T>
@@ -52,6 +58,7 @@ inline DevParams<T> make_dev_params(const HostParams& h) {
     d.hold_frozen = h.hold_frozen;
     d.q_gyro = (h.qd[3] != 0.0 || h.qd[4] != 0.0 || h.qd[5] != 0.0 || h.q_gyro_any) ? 1 : 0;
     d.jfull = (d.q_gyro || h.keep_jac) ? 1 : 0;
+    d.quirks = h.quirks;
     return d;
 }
 
@@ -159,7 +166,7 @@ hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double*
                              hipStream_t stream);
 
 // Fx [B,24,24] and Fi [B,24,13] of the predict whose full record (85 block words) is J[ip]
-hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, hipStream_t stream);
+hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, int quirks, hipStream_t stream);
 
 // eskf_noise.hip -- kind: 0 = normals f64, 1 = normals f32, 2 = raw Philox words (uint32 x 4 per triple)
 hipError_t launch_randn(int kind, uint64_t seed, int64_t first_instance, int64_t n_instances, int64_t first_step,

@@ -407,7 +407,7 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
 #pragma unroll
             for (int i = 0; i < 3; ++i) { e69[i] = pd.src[6 + i]; e1518[i] = pd.src[15 + i]; e2124[i] = pd.src[21 + i]; }
             T dqc[4], qcn[4];
-            quat_about_axis(norm3(e2124), e69, dqc);   // sic (state.py:124)
+            quat_about_axis(norm3(e2124), (prm.quirks & QK_Q3) ? e69 : e2124, dqc);   // sic (state.py:124) unless Q3 is off
             quat_mul(qc, dqc, qcn);
             quat_nrm(qcn);
 #pragma unroll
@@ -453,7 +453,7 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
             }
             T u[3], C_om[3], wc[3], Rc[9], RcS[9], Rcn[9];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) u[i] = om_o[i] + z6[i] * notch[1];
+            for (int i = 0; i < 3; ++i) u[i] = ((prm.quirks & QK_Q9) ? om_o[i] : (om_o[i] + om_n[i]) * T(0.5)) + z6[i] * notch[1];   // (Q9)
             mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
 #pragma unroll
             for (int i = 0; i < 3; ++i) wc[i] = dt * C_om[i];
@@ -497,7 +497,7 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
             T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
             T flag = T(0);
             if (nv > T(1)) { nv = T(1); flag = T(1); }
-            const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+            const T ang = residual_angle(nv, prm.quirks);             // half-angle residual (Quaternion.py:138-147) unless Q6 is off
             const T f = (nv == T(0)) ? T(0) : ang / nv;
             EP_WAIT_BEGIN()
             wait_ge(flags + F_RA_EP, e + 1);
@@ -1022,8 +1022,8 @@ static int epochs_kernel_block_typed(int lpi, const StepArgs& a, const DevParams
         if (hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
         return (size_t)lim >= ep::Lay<double, 12>::BYTES;
     }();
-    const bool ok = lds_ok && g_epochs != 0 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 &&
-                    a.B < 0x7fffffffLL;
+    const bool ok = lds_ok && g_epochs != 0 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count && !prm.jfull && !prm.q_gyro &&
+                    (prm.quirks & QK_Q1) && a.B > 0 && a.B < 0x7fffffffLL;
     return ok ? 2 * epochs_nc(a.B) : 0;
 }
 int epochs_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {

@@ -174,6 +174,13 @@ __device__ __forceinline__ void quat_about_axis(T angle, const T* axis, T* q) {
     quat_nrm(q);
 }
 
+// Quaternion.angle (Quaternion.py:138-147) of the unit error quaternion with vector part of length nv: asin(nv), HALF the
+// rotation angle (quirk Q6) -- the full angle when the quirk is switched off.  (v1: times one, the same bits.)
+template <typename T>
+__device__ __forceinline__ T residual_angle(T nv, int quirks) {
+    const T k6 = (quirks & QK_Q6) ? T(1) : T(2);
+    return k6 * t_asin(nv);
+}
 // ----------------------------------------------------------------------------------
 // probe kinematics in closed form (models/Probe.py:147-167)
 // ----------------------------------------------------------------------------------
@@ -297,7 +304,7 @@ __device__ __forceinline__ void predict_scalar(State<T>& s, const DevParams<T>& 
             for (int i = 0; i < 3; ++i) acc_avg[i] = (a1[i] + a2[i]) * T(0.5);      // equations.py:47
             T u[3], C_om[3], cr[3], Rcr[3], wc[3], RcS[9], Rcn[9];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) u[i] = s.om_o[i] + z6[i] * s.notch[1];
+            for (int i = 0; i < 3; ++i) u[i] = ((prm.quirks & QK_Q9) ? s.om_o[i] : om_avg[i]) + z6[i] * s.notch[1];   // (Q9: om_old, not the average)
             mat3T_vec(RBC, u, C_om);                                                // equations.py:50
             cross3(om_avg, pB, cr);                                                 // BB_v_CB == 0
             mat3_vec(R, cr, Rcr);
@@ -698,7 +705,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
 #pragma unroll
             for (int i = 0; i < 3; ++i) s.notch[i] += epend[15 + i];
         } else {
-            inject_error(s, epend);
+            inject_error(s, epend, prm.quirks);
         }
     }
     if (jac_role) {
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(128, 2) void eskf_pre_kernel(StepArgs a, DevParams<
         T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
         T flag = T(0);
         if (nv > T(1)) { nv = T(1); flag = T(1); }
-        const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+        const T ang = residual_angle(nv, prm.quirks);             // half-angle residual (Quaternion.py:138-147) unless Q6 is off
         const T f = (nv == T(0)) ? T(0) : ang / nv;
         T* gr = reinterpret_cast<T*>(a.J) + bo * JW + J_RES;      // (record of the launch's first predict)
         T r[7];
@@ -1206,6 +1213,12 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
         for (int i = 0; i < 4; ++i) qc[i] = X(22 + i);
         T e69[3], e1518[3], e2124[3];
         if (e_wanted) { load_epend(a, b, 6, 3, e69, e_lds, sE_row); load_epend(a, b, 15, 3, e1518, e_lds, sE_row); load_epend(a, b, 21, 3, e2124, e_lds, sE_row); }
+        T om_w[3] = {om_o[0], om_o[1], om_o[2]};        // what the camera attitude is propagated with: om_old (quirk Q9) ...
+        if (!(prm.quirks & QK_Q9)) {                    // ... or the average of the old and the new sample
+            const int64_t so = a.imu_stride ? b * 3 : 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) om_w[i] = (om_o[i] + reinterpret_cast<const T*>(a.om)[so + i]) * T(0.5);
+        }
         T qraw[4] = {T(0), T(0), T(0), T(1)}, ang_notch = T(0);
         if (a.do_update) {
             const int64_t mo = a.meas_stride ? b : 0;
@@ -1216,7 +1229,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
         }
         if (inject_now) {
             T dqc[4], qcn[4];
-            quat_about_axis(norm3(e2124), e69, dqc);   // sic (state.py:124)
+            quat_about_axis(norm3(e2124), (prm.quirks & QK_Q3) ? e69 : e2124, dqc);   // sic (state.py:124) unless Q3 is off
             quat_mul(qc, dqc, qcn);
             quat_nrm(qcn);
 #pragma unroll
@@ -1252,7 +1265,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
         }
         T u[3], C_om[3], wc[3], RcS[9], Rcn[9], qcn[4];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) u[i] = om_o[i] + z6[i] * notch[1];
+        for (int i = 0; i < 3; ++i) u[i] = om_w[i] + z6[i] * notch[1];
         mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
 #pragma unroll
         for (int i = 0; i < 3; ++i) wc[i] = dt * C_om[i];
@@ -1269,7 +1282,7 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
             quat_nrm(qe);
             T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
             if (nv > T(1)) { nv = T(1); flag = T(1); }
-            const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+            const T ang = residual_angle(nv, prm.quirks);             // half-angle residual (Quaternion.py:138-147) unless Q6 is off
             const T f = (nv == T(0)) ? T(0) : ang / nv;
 #pragma unroll
             for (int i = 0; i < 3; ++i) r[i] = f * qe[i];
@@ -1594,7 +1607,7 @@ __global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevPar
     load_imu_sample(a, 0, b, dt, om_n, acc_n);
     if (inject_now) {
         T dqc[4], qcn[4];
-        quat_about_axis(norm3(e2124), e69, dqc);   // sic (state.py:124)
+        quat_about_axis(norm3(e2124), (prm.quirks & QK_Q3) ? e69 : e2124, dqc);   // sic (state.py:124) unless Q3 is off
         quat_mul(qc, dqc, qcn);
         quat_nrm(qcn);
 #pragma unroll
@@ -1640,7 +1653,7 @@ __global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevPar
         }
         T u[3], C_om[3], wc[3], Rc[9], RcS[9], Rcn[9];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) u[i] = om_o[i] + z6[i] * notch[1];
+        for (int i = 0; i < 3; ++i) u[i] = ((prm.quirks & QK_Q9) ? om_o[i] : (om_o[i] + om_n[i]) * T(0.5)) + z6[i] * notch[1];   // (Q9)
         mat3T_vec(RBC, u, C_om);                                                    // equations.py:50
 #pragma unroll
         for (int i = 0; i < 3; ++i) wc[i] = dt * C_om[i];
@@ -1671,7 +1684,7 @@ __global__ __launch_bounds__(128, 2) void eskf_nominal_kernel(StepArgs a, DevPar
         T nv = t_sqrt(qe[0] * qe[0] + qe[1] * qe[1] + qe[2] * qe[2]);
         T flag = T(0);
         if (nv > T(1)) { nv = T(1); flag = T(1); }
-        const T ang = t_asin(nv);                             // half-angle residual (Quaternion.py:138-147)
+        const T ang = residual_angle(nv, prm.quirks);             // half-angle residual (Quaternion.py:138-147) unless Q6 is off
         const T f = (nv == T(0)) ? T(0) : ang / nv;
         T r[7];
 #pragma unroll
@@ -1756,11 +1769,11 @@ __global__ __launch_bounds__(128, 4) void eskf_jac_kernel(StepArgs a, DevParams<
 
 // ---- error injection: ErrorState.from_array (state.py:105-129) + State.__add__ (state.py:46-60)
 template <typename T>
-__device__ __forceinline__ void inject_error(State<T>& s, const T* e) {
+__device__ __forceinline__ void inject_error(State<T>& s, const T* e, const int quirks) {
     T th[3] = {e[6], e[7], e[8]}, thc[3] = {e[21], e[22], e[23]};
     T dq[4], dqc[4], qn[4], qcn[4];
     quat_about_axis(norm3(th), th, dq);
-    quat_about_axis(norm3(thc), th, dqc);   // sic (state.py:124)
+    quat_about_axis(norm3(thc), (quirks & QK_Q3) ? th : thc, dqc);   // sic (state.py:124: the axis is the IMU's delta-theta) unless Q3 is off
     quat_mul(s.q, dq, qn);
     quat_nrm(qn);
     quat_mul(s.qc, dqc, qcn);
@@ -1787,7 +1800,7 @@ __global__ __launch_bounds__(256) void eskf_post_kernel(StepArgs a, DevParams<T>
     T* xs = reinterpret_cast<T*>(a.xs);
     State<T> s;
     load_state(xs, a.B, b, s);
-    inject_error(s, reinterpret_cast<const T*>(a.e) + b * 24);
+    inject_error(s, reinterpret_cast<const T*>(a.e) + b * 24, prm.quirks);
     store_state(xs, a.B, b, s);
 }
 
@@ -2776,7 +2789,11 @@ struct JRegs {
 };
 // dst[0:24] = Fx v and o = Fx c: the operations of fx_apply_store / fx_apply_col in the same order (the two
 // lane layouts give the same bits), with the Jacobian entries as DPP operands instead of LDS reads
-template <typename T>
+// Q1 (symbols.py:103,107 / Filter.py:279-285): the v1 source places the columns of the camera rows' Jacobian
+// after err_q one position per VARIABLE instead of one per error-state column -- delta-p_C's identity lands in columns 16:19
+// (notch rate, notch acceleration, p_C x), Em in 19:22, and the ones of I_24 at (22,22), (23,23) survive.  Q1 = false: the
+// columns where those variables live -- identity at 18:21, Em at 21:24, nothing from columns 16:18.
+template <typename T, bool Q1 = true>
 __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&v)[24], T* dst, bool active) {
     {
         T o[9];
@@ -2809,7 +2826,7 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
         T o[3];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            T u = v[16 + r];
+            T u = v[(Q1 ? 16 : 18) + r];
             J.template mac<J_DT>(u, v[3 + r]);
             J.template mac<J_BM + 3 * r>(u, v[6]); J.template mac<J_BM + 3 * r + 1>(u, v[7]); J.template mac<J_BM + 3 * r + 2>(u, v[8]);
             static_for<0, 6>([&](auto K) { J.template mac<J_CM + 6 * r + decltype(K)::value>(u, v[9 + decltype(K)::value]); });
@@ -2827,9 +2844,10 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
             T w = T(0);
             J.template mac<J_DM + 4 * r + 3>(w, v[15]);
             J.template mac<J_DM + 4 * r>(w, v[9]); J.template mac<J_DM + 4 * r + 1>(w, v[10]); J.template mac<J_DM + 4 * r + 2>(w, v[11]);
-            J.template mac<J_EM + 3 * r>(w, v[19]); J.template mac<J_EM + 3 * r + 1>(w, v[20]); J.template mac<J_EM + 3 * r + 2>(w, v[21]);
-            if (r == 1) w += v[22];
-            if (r == 2) w += v[23];
+            constexpr int e0 = Q1 ? 19 : 21;
+            J.template mac<J_EM + 3 * r>(w, v[e0]); J.template mac<J_EM + 3 * r + 1>(w, v[e0 + 1]); J.template mac<J_EM + 3 * r + 2>(w, v[e0 + 2]);
+            if (Q1 && r == 1) w += v[22];
+            if (Q1 && r == 2) w += v[23];
             o[r] = w;
         });
         if (active) {
@@ -2838,7 +2856,7 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
         }
     }
 }
-template <typename T>
+template <typename T, bool Q1 = true>
 __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col, T (&o)[24]) {
     T u[3], w[3];
     {   // inputs 0..8
@@ -2872,8 +2890,10 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
         o[15] = o15;
         o[16] = o16;
         o[17] = c[8];
-        u[0] += c[7];                       // c[16 + r], r = 0, 1 (r = 2 is input 18)
-        u[1] += c[8];
+        if constexpr (Q1) {
+            u[0] += c[7];                   // c[16 + r], r = 0, 1 (r = 2 is input 18)
+            u[1] += c[8];
+        }
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
             static_for<0, 6>([&](auto K) { J.template mac<J_CM + 6 * r + decltype(K)::value>(u[r], c[decltype(K)::value]); });
@@ -2887,13 +2907,21 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
         T c[6];
 #pragma unroll
         for (int k = 0; k < 6; ++k) c[k] = lds_load1(col + (18 + k) * PS);
-        u[2] += c[0];
-        static_for<0, 3>([&](auto R) {
-            constexpr int r = decltype(R)::value;
-            J.template mac<J_EM + 3 * r>(w[r], c[1]); J.template mac<J_EM + 3 * r + 1>(w[r], c[2]); J.template mac<J_EM + 3 * r + 2>(w[r], c[3]);
-        });
-        w[1] += c[4];
-        w[2] += c[5];
+        if constexpr (Q1) {
+            u[2] += c[0];
+            static_for<0, 3>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                J.template mac<J_EM + 3 * r>(w[r], c[1]); J.template mac<J_EM + 3 * r + 1>(w[r], c[2]); J.template mac<J_EM + 3 * r + 2>(w[r], c[3]);
+            });
+            w[1] += c[4];
+            w[2] += c[5];
+        } else {
+            u[0] += c[0]; u[1] += c[1]; u[2] += c[2];
+            static_for<0, 3>([&](auto R) {
+                constexpr int r = decltype(R)::value;
+                J.template mac<J_EM + 3 * r>(w[r], c[3]); J.template mac<J_EM + 3 * r + 1>(w[r], c[4]); J.template mac<J_EM + 3 * r + 2>(w[r], c[5]);
+            });
+        }
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) { o[18 + r] = u[r]; o[21 + r] = w[r]; }
@@ -3001,7 +3029,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-template <typename T, bool PIN, int LPI, bool SLIM, bool WAVE = false>
+template <typename T, bool PIN, int LPI, bool SLIM, bool WAVE = false, bool Q1 = true>
 __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevParams<T>& prm_in, T* smem, const int vblock, const int lane,
                                               const T* jpre = nullptr, const int kstep = -1, const bool e_keep = false, T* e_out = nullptr,
                                               const bool p_in_lds = false, const bool p_keep = false) {
@@ -3036,6 +3064,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     static_assert(LPI == 32 || LPI == 24, "lane layouts: 32 or 24 lanes per instance");
     static_assert(!SLIM || LPI == 32, "SLIM: 32 lanes per instance");
     static_assert(!WAVE || SLIM, "WAVE: the slim build");
+    static_assert(Q1 || (LPI == 32 && SLIM && !PIN && !WAVE), "Q1 switched off: the slim 32-lane kernel of the two-kernel step only");
     constexpr int G = LPI == 32 ? 2 : 8;    // instances per block
     constexpr int TV = LPI == 32 ? 0 : 1;   // table variant
     // (with per-instance noise the 24-word noise record follows the residual: 664 words, 15 wavefronts per CU)
@@ -3205,10 +3234,10 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     // one predict on the row-resident P with the Jacobian record that sits in LDS
 #define ESKF_PREDICT_ROWS()                                                                        \
     {                                                                                              \
-        if constexpr (DPPJ) fx_apply_store_dpp(Jr, p, sB + row * PS, active);                      \
+        if constexpr (DPPJ) fx_apply_store_dpp<T, Q1>(Jr, p, sB + row * PS, active);               \
         else fx_apply_store(sJ, p, sB + row * PS, active);   /* column `row` of Fx P = row `row` of W = P Fx^T */ \
         gsync();                                                                              \
-        if constexpr (DPPJ) fx_apply_col_dpp(Jr, sB + row, p);                                     \
+        if constexpr (DPPJ) fx_apply_col_dpp<T, Q1>(Jr, sB + row, p);                              \
         else fx_apply_col(sJ, sB + row, p);  /* column `row` of Fx P Fx^T = row `row` of P' */     \
         refresh_args();                                                                            \
         noise_rows<T, PIN, !SLIM, LPI == 32>(prm, sJ, sN, row, p);                                 \
@@ -3671,12 +3700,12 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
 #undef ESKF_PREDICT_ROWS
 }
 
-template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false>
+template <typename T, bool PIN = false, int LPI = 32, bool SLIM = false, bool Q1 = true>
 __global__ __launch_bounds__(LPI == 32 ? 64 : 192, SLIM ? 4 : ROWS_WAVES) void eskf_cov_rows_kernel(StepArgs a, DevParams<T> prm) {
     constexpr int G = LPI == 32 ? 2 : 8;
     constexpr int REGION = SLIM ? (PIN ? 664 : 640) : PIN ? rowk::R_REGION_PIN : rowk::R_REGION;
     __shared__ __attribute__((aligned(16))) T smem[G * REGION];
-    cov_rows_body<T, PIN, LPI, SLIM>(a, prm, smem, (int)blockIdx.x + (int)(a.sub_first / G), (int)threadIdx.x);
+    cov_rows_body<T, PIN, LPI, SLIM, false, Q1>(a, prm, smem, (int)blockIdx.x + (int)(a.sub_first / G), (int)threadIdx.x);
 }
 
 // ----------------------------------------------------------------------------------
@@ -4119,7 +4148,7 @@ __global__ __launch_bounds__(256) void eskf_update_mse_kernel(int64_t B, const T
 // ----------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void eskf_jacobians_kernel(int64_t B, const T* __restrict__ J, T* __restrict__ Fx,
-                                                             T* __restrict__ Fi) {
+                                                             T* __restrict__ Fi, int quirks) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= B * 24) return;
     const int64_t b = tid / 24;
@@ -4144,14 +4173,18 @@ __global__ __launch_bounds__(256) void eskf_jacobians_kernel(int64_t B, const T*
         fx[3 + q] = dt;
         for (int k = 0; k < 3; ++k) fx[6 + k] = j[J_BM + 3 * q + k];
         for (int k = 0; k < 6; ++k) fx[9 + k] = j[J_CM + 6 * q + k];
-        fx[16 + q] = T(1);
+        fx[((quirks & QK_Q1) ? 16 : 18) + q] = T(1);
         for (int k = 0; k < 3; ++k) fi[3 + k] = j[J_N6 + 3 * q + k];
     } else {
         const int q = r - 21;
         for (int k = 0; k < 3; ++k) fx[9 + k] = j[J_DM + 4 * q + k];
         fx[15] = j[J_DM + 4 * q + 3];
-        for (int k = 0; k < 3; ++k) fx[19 + k] = j[J_EM + 3 * q + k];
-        if (q > 0) fx[21 + q] = T(1);
+        if (quirks & QK_Q1) {
+            for (int k = 0; k < 3; ++k) fx[19 + k] = j[J_EM + 3 * q + k];
+            if (q > 0) fx[21 + q] = T(1);
+        } else {
+            for (int k = 0; k < 3; ++k) fx[21 + k] = j[J_EM + 3 * q + k];
+        }
         for (int k = 0; k < 3; ++k) fi[3 + k] = j[J_N6 + 9 + 3 * q + k];
     }
     T* ox = Fx + (b * 24 + r) * 24;
@@ -4181,6 +4214,7 @@ template <typename T, int LPI, bool PIN = false>
 static hipError_t launch_cov_t(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
     constexpr int G = 64 / LPI;
     if (a.sub_count) return hipErrorInvalidValue;          // (the LDS-image kernel covers the whole batch)
+    if (!(prm.quirks & QK_Q1) && a.n_pred > 0) return hipErrorInvalidValue;     // (it only knows the v1 column layout of the camera rows)
     // rounds per wave: enough waves to keep every CU's LDS full several times over, few enough
     // that most HBM round trips hide behind the previous instance's arithmetic
     StepArgs b = a;
@@ -4202,10 +4236,18 @@ static hipError_t launch_cov_rows(const StepArgs& a, const DevParams<T>& prm, hi
     const int64_t blocks = ((a.sub_count ? a.sub_count : a.B) + G - 1) / G;
     if constexpr (LPI == 32) {
         if (!prm.q_gyro) {      // no gyro block in Q (the normal case): the four-waves-per-SIMD build of the same kernel
+            if constexpr (!PIN) {
+                if (!(prm.quirks & QK_Q1) && a.n_pred > 0) {    // the camera rows' columns where their variables live (quirk Q1 off)
+                    hipLaunchKernelGGL((eskf_cov_rows_kernel<T, false, 32, true, false>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
+                    return hipGetLastError();
+                }
+            }
+            if (!(prm.quirks & QK_Q1) && a.n_pred > 0) return hipErrorInvalidValue;
             hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, 32, true>), dim3((unsigned)blocks), dim3(64), 0, stream, a, prm);
             return hipGetLastError();
         }
     }
+    if (!(prm.quirks & QK_Q1) && a.n_pred > 0) return hipErrorInvalidValue;     // (the other builds only know the v1 column layout)
     hipLaunchKernelGGL((eskf_cov_rows_kernel<T, PIN, LPI>), dim3((unsigned)blocks), dim3(LPI == 32 ? 64 : 192), 0, stream, a, prm);
     return hipGetLastError();
 }
@@ -4273,7 +4315,7 @@ static bool step_kernel_covers(int lpi, const StepArgs& a, const DevParams<T>& p
     // (per-instance noise: the 16-instance blocks only -- a population is a small batch, and the 85 KB images are one block per CU)
     const int rounds = step_kernel_rounds(a.B, a.noise != nullptr);
     return lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && !a.K_out &&
-           (!a.noise || rounds == 1) && !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
+           (!a.noise || rounds == 1) && !a.sub_count && !prm.jfull && !prm.q_gyro && (prm.quirks & QK_Q1) && a.B > 0 && a.B < 0x7fffffffLL;
 }
 template <typename T>
 static hipError_t launch_step_kernel(const StepArgs& a, const DevParams<T>& prm, hipStream_t stream) {
@@ -4315,7 +4357,7 @@ static int run_kernel_block_typed(int lpi, const StepArgs& a, const DevParams<T>
     static const bool lds_ok = device_lds_fits((size_t)8 * 2 * 664 * sizeof(double));
     const int rounds = run_kernel_rounds(a.B, a.noise != nullptr);
     const bool ok = lds_ok && rounds != 0 && !g_pre_legacy && a.n_pred == 1 && lpi == 1 && (!a.noise || rounds == 1) && !a.K_out &&
-                    !a.sub_count && !prm.jfull && !prm.q_gyro && a.B > 0 && a.B < 0x7fffffffLL;
+                    !a.sub_count && !prm.jfull && !prm.q_gyro && (prm.quirks & QK_Q1) && a.B > 0 && a.B < 0x7fffffffLL;
     return ok ? 16 * rounds : 0;
 }
 int run_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
@@ -4574,14 +4616,14 @@ hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double*
     return hipGetLastError();
 }
 
-hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, hipStream_t stream) {
+hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* Fx, void* Fi, int quirks, hipStream_t stream) {
     if (B <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((B * 24 + 255) / 256);
     const size_t off = (size_t)ip * (size_t)B * JW;
     if (dtype == 0)
-        hipLaunchKernelGGL(eskf_jacobians_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, (const double*)J + off, (double*)Fx, (double*)Fi);
+        hipLaunchKernelGGL(eskf_jacobians_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, (const double*)J + off, (double*)Fx, (double*)Fi, quirks);
     else
-        hipLaunchKernelGGL(eskf_jacobians_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)J + off, (float*)Fx, (float*)Fi);
+        hipLaunchKernelGGL(eskf_jacobians_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)J + off, (float*)Fx, (float*)Fi, quirks);
     return hipGetLastError();
 }
 

@@ -19,8 +19,11 @@
  *    (dvi_ekf/filter/state.py:11-86); error state = 24 (state.py:89-129).
  *  - behaviour: the arithmetic is that of the v1 source including its quirks Q1-Q10 of SURVEY.md
  *    App. A.6 (column cursor of the camera rows, v_tr := p_tr, Jacobians at n = sigma, half-angle
- *    residual, stale R_WB_old, ...), which are NOT switchable: the reference's saved trajectory pins
- *    every one of them.  The only plumbing switch is dvi_eskf_params.hold_frozen (G1).
+ *    residual, stale R_WB_old, ...): the reference's saved trajectory pins every one of them, and that
+ *    is the default.  The four a maintainer of the reference would fix first can be switched off per
+ *    handle, dvi_eskf_params.quirks_fixed (DVI_ESKF_FIX_Q1 / Q3 / Q6 / Q9 below) -- there is no reference
+ *    artefact for a "fixed" filter; those variants are checked against the restatement with the same quirk
+ *    switched off (oracle/eskf_ref.py, tests/test_gpu_quirks.py).  The plumbing switch is hold_frozen (G1).
  *
  * HIP graphs.  predict / update / step / epoch / step_from / run_epochs / run_epochs_from / flush / get_* / copy_state only
  * enqueue kernels and async copies on `stream` and may be recorded with hipStreamBeginCapture and
@@ -87,7 +90,21 @@ typedef struct {
     double sigma_a[3];    /* accelerometer noise std (config.py:116-120)                   */
     double sigma_om[3];   /* gyro noise std (config.py:106-113); the Jacobians are evaluated
                              at n_om = sigma_om (Filter.py:330-333)                        */
+    int32_t quirks_fixed; /* 0: the v1 source as it is.  DVI_ESKF_FIX_* bits switch a quirk off: */
 } dvi_eskf_params;
+/* Q1, kinematics/symbols.py:103,107 + Filter.py:279-285: the columns of the camera rows' Jacobian are placed one per
+ *     VARIABLE (err_q counts as one) instead of one per error-state column: delta-p_C's identity lands in columns 16:19, the
+ *     delta-theta_C block in 19:22.  Fixed: identity at 18:21, the block at 21:24.  Predicts of such a handle run through the
+ *     row-resident covariance kernel only (default lanes, shared noise model, no gyro block in Q, no gain output together
+ *     with a predict: DVI_ESKF_EINVAL otherwise) and one launch sequence per step / epoch.
+ * Q3, filter/state.py:124: the camera error quaternion is built about the IMU's delta-theta axis.  Fixed: about delta-theta_C.
+ * Q6, tools/Quaternion.py:138-147: the rotation residual is asin|v| x axis, HALF the rotation angle.  Fixed: the full angle.
+ * Q9, kinematics/equations.py:50,86: the camera attitude is propagated with om_old.  Fixed: with the averaged rate, as the
+ *     IMU attitude is. */
+#define DVI_ESKF_FIX_Q1 1
+#define DVI_ESKF_FIX_Q3 2
+#define DVI_ESKF_FIX_Q6 4
+#define DVI_ESKF_FIX_Q9 8
 
 /* Filter.__init__ (Filter.py:34-93): allocates device state for `batch` independent
  * filter instances on HIP device `device`.  dtype: DVI_ESKF_F64 | DVI_ESKF_F32. */
