@@ -299,7 +299,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (configs #3 and #5, the 10:1 schedule, the small batch, the 1-thread oracle)")
     ap.add_argument("--horizon", type=int, default=16, help="pair-steps between state restores")
-    ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident; 64/32/24/16/12/8 = LDS-image kernel with that many lanes per instance)")
+    ap.add_argument("--lanes", type=int, default=0, help="covariance kernel selector (0 = library default: row-resident, 32 lanes per instance; 2 = row-resident, 24 lanes; 32 = LDS-image kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--restore-copy", action="store_true",
                     help="restart a horizon by copying the snapshot into the filter (176 MB device-to-device) and stepping in "

@@ -907,7 +907,7 @@ void* dvi_eskf_raw_x(dvi_eskf* h) { return h ? h->d_x : nullptr; }
 
 int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes) {
     if (!h) return DVI_ESKF_EINVAL;
-    if (lanes != 1 && lanes != 2 && lanes != 64 && lanes != 32 && lanes != 24 && lanes != 16 && lanes != 12 && lanes != 8) return DVI_ESKF_EINVAL;
+    if (lanes != 1 && lanes != 2 && lanes != 32) return DVI_ESKF_EINVAL;
     h->lpi = lanes;
     return DVI_ESKF_OK;
 }

@@ -108,9 +108,6 @@ __device__ __forceinline__ void wait_all_ge(const int* counters, int n, int need
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void publish(int* p, int v) {
-#ifdef ESKF_X_EP_FENCE      // experiment: every LDS / memory operation of the wavefront has completed before the counter moves
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
     asm volatile("" ::: "memory");
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");

@@ -54,17 +54,9 @@ namespace eskf {
 // ----------------------------------------------------------------------------------
 // small math on register arrays
 // ----------------------------------------------------------------------------------
-#ifdef ESKF_X_CHEAP_SINCOS   // timing experiment only (wrong numbers): what the trigonometry costs
-__device__ __forceinline__ void t_sincos(double a, double& s, double& c) { s = a; c = fma(-0.5 * a, a, 1.0); }
-#else
 __device__ __forceinline__ void t_sincos(double a, double& s, double& c) { sincos(a, &s, &c); }
-#endif
 __device__ __forceinline__ void t_sincos(float a, float& s, float& c) { sincosf(a, &s, &c); }
-#ifdef ESKF_X_CHEAP_SQRT     // timing experiment only: raw v_sqrt_f64 (~1e-8 relative)
-__device__ __forceinline__ double t_sqrt(double a) { return __builtin_amdgcn_sqrt(a); }
-#else
 __device__ __forceinline__ double t_sqrt(double a) { return sqrt(a); }
-#endif
 __device__ __forceinline__ float t_sqrt(float a) { return sqrtf(a); }
 __device__ __forceinline__ double t_asin(double a) { return asin(a); }
 __device__ __forceinline__ float t_asin(float a) { return asinf(a); }
@@ -584,12 +576,7 @@ __device__ __forceinline__ void load_imu_sample(const StepArgs& a, int ip, int64
 // (pieces of up to four records per instruction) 183 us.
 template <typename P>
 __device__ __forceinline__ void st_piece(P* dst, const P& v) {
-#ifdef ESKF_X_NT_RECORDS    // experiment: the records are written once and read once by the next kernel -- non-temporal stores
-    typedef unsigned __attribute__((ext_vector_type(4))) u4;
-    __builtin_nontemporal_store(__builtin_bit_cast(u4, v), reinterpret_cast<u4*>(dst));
-#else
     *dst = v;
-#endif
 }
 template <typename T, int JS>
 __device__ __forceinline__ void store_records(const T* sJ, T* gJ, int nrec, int lane, int first = 0) {
@@ -1055,11 +1042,7 @@ __device__ __forceinline__ void load_epend(const StepArgs& a, int64_t b, int i0,
         return;
     }
 #pragma unroll
-#ifdef ESKF_X_COALESCED_E   // timing experiment only (wrong words): the pending error state read lane-contiguously
-    for (int i = 0; i < n; ++i) dst[i] = reinterpret_cast<const T*>(a.e)[(b & ~(int64_t)63) * 24 + (i0 + i) * 64 + (b & 63)];
-#else
     for (int i = 0; i < n; ++i) dst[i] = reinterpret_cast<const T*>(a.e)[b * 24 + i0 + i];
-#endif
 }
 // KEEP (eskf_step_kernel): the block's first NI lanes carry its NI instances and the records STAY in the staging rows --
 // the covariance rounds of the same block take them from there; nothing is written to a.J.
@@ -1085,11 +1068,6 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
     const int64_t b = live ? b_raw : b_last;           // tail lanes recompute the block's last instance, write nothing
     const T* xi = reinterpret_cast<const T*>(a.xs_src);
     const int64_t B = a.B;
-#ifdef ESKF_X_STAGGER       // experiment: every other block starts ESKF_X_STAGGER x 0.5 us late
-    if (vblock & 1) {
-        for (int k = 0; k < ESKF_X_STAGGER; ++k) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     auto X = [&](int w) { return xi[(int64_t)w * B + b]; };
     // deferred injection: device state, see eskf_pre_kernel
     const T* sE_row = sJ + staging_row_word<IMG>(NI == 64 || lane < NI ? lane : NI - 1) + E_ROW;
@@ -1395,10 +1373,8 @@ __device__ __forceinline__ void pre4_body(const StepArgs& a, const DevParams<T>&
         T* gJ = reinterpret_cast<T*>(a.J) + b0 * JW;
         const int nrec = (a.B - b0 < 64) ? (int)(a.B - b0) : 64;
         const int first = role * 16, last = (first + 16 < nrec) ? first + 16 : nrec;
-#ifndef ESKF_X_NO_RECSTORE  // timing experiment only: the records never leave the block
         if (prm.jfull) store_records<T, J_FULL>(sJ, gJ, last, lane, first);
         else store_records<T, J_CORE>(sJ, gJ, last, lane, first);
-#endif
     }
     if (role == 0) ESKF_STAMP(6)
 #ifdef ESKF_X_STAMPS
@@ -3009,16 +2985,7 @@ __device__ const RowsTables kRowsTables = make_rows_tables();
 #ifndef ESKF_PACKED_IMAGE
 #define ESKF_PACKED_IMAGE 1
 #endif
-#ifdef ESKF_X_JHOT          // timing experiment only (wrong numbers): every wavefront reads the records of instances 0 / 1 --
-#define ESKF_X_JHOT_SEL(A, B) (A)   // what the covariance kernel costs when its Jacobian records cost no traffic
-#else
-#define ESKF_X_JHOT_SEL(A, B) (B)
-#endif
-#ifdef ESKF_X_NT_JLOADS     // experiment: records are read exactly once
-#define ESKF_LDJ(p) __builtin_nontemporal_load(p)
-#else
 #define ESKF_LDJ(p) (*(p))
-#endif
 // WAVE (eskf_step_kernel): the wavefront is one of several of its block, each working through pairs of instances on its
 // own: the exchanges through LDS are wave-local (LDS instructions of one wavefront execute in order -- only the
 // compiler has to be kept from moving them across), the region is the 600-word image alone, and the first predict's
@@ -3111,9 +3078,9 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         if constexpr (LPI == 32) {                                                                 \
             /* wave-uniform base + unsigned 32-bit lane offset, as for the rows; only the third word of a lane can lie \
                in the padding of the record (words >= 64 + lane), which is not fetched */                      \
-            const int i0_ = ESKF_X_JHOT_SEL(0, vblock * G);                                        \
+            const int i0_ = vblock * G;                                                            \
             const char* gJw_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.J) + ((int64_t)(IP) * a.B + i0_) * JW); \
-            const unsigned jo_ = (unsigned)ESKF_X_JHOT_SEL(grp, (INST) - i0_) * (unsigned)(JW * sizeof(T)); \
+            const unsigned jo_ = (unsigned)((INST) - i0_) * (unsigned)(JW * sizeof(T));           \
             const unsigned lo_ = jo_ + (unsigned)lj_ * (unsigned)sizeof(T);                        \
             static_assert(NJ == 3 && J_CORE - 1 >= 64, "three words per lane, the first two never padding"); \
             DST[0] = ESKF_LDJ(reinterpret_cast<const T*>(gJw_ + (size_t)lo_));                      \
@@ -3256,9 +3223,6 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         T j0[NJ];
         T2 r0;
         r0.x = r0.y = T(0);
-#ifdef ESKF_X_PRIO
-        __builtin_amdgcn_s_setprio(3);      // a new wavefront is the youngest on its SIMD: let it get its requests out
-#endif
 #if ESKF_ROWS_VIA_LDS
         // The packed record arrives as coalesced 16-byte pieces (five per lane in fp64, three in fp32), goes into LDS in
         // its own order and is gathered from there: P[row][j] = packed[max(row, j)][min(row, j)], the lane set of either
@@ -3315,10 +3279,6 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         ESKF_ISSUE_ROW()
         ESKF_LOAD_J(j0, r0, inst, 0)
 #endif
-#ifdef ESKF_X_PRIO
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_setprio(0);
-#endif
         ESKF_STAGE_J(j0, r0)
         if (PIN || !SLIM) gsync();      // (what has been staged -- noise record, N6 rows -- is visible to every lane)
     } else {
@@ -3346,14 +3306,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     }
 
     // ================================ predict(s) =======================================
-    // (ESKF_X_NO_PREDICT / ESKF_X_NO_UPDATE, `make EXTRA=-D...`: timing builds with a part compiled out -- what the
-    //  memory skeleton of the kernel costs on its own, profiles/r03_cov_phase_variants.json; wrong results, of course)
-#ifdef ESKF_X_NO_PREDICT
-    const int n_pred_run = 0;
-    asm volatile("" : : "v"(Jr.X[0]), "v"(Jr.Y[1]), "v"(Jr.Y[2]));      // (the record is still fetched)
-#else
     const int n_pred_run = a.n_pred;
-#endif
     if constexpr (DPPJ) {
         // epochs: the record of the next predict is requested before this one is computed (six registers)
         // and put in place after it; the last (or only) predict of a launch has nothing to fetch
@@ -3407,11 +3360,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     T e = T(0);                             // component `row` of the error state
     int status = 0;
     bool fail = false;
-#ifdef ESKF_X_NO_UPDATE
-    const bool do_update_run = false;
-#else
     const bool do_update_run = a.do_update != 0;
-#endif
     if (do_update_run) {
         constexpr bool DPPU = LPI == 32;
         if constexpr (DPPU) status = (dpp_bcast<7>(Xres) != T(0)) ? DVI_STATUS_NONFINITE : 0;
@@ -3624,9 +3573,6 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
 #endif
     ESKF_CSTAMP(4)
     // ---- store: rows -> lower-triangle image -> packed record (16-byte stores) ----------------
-#if defined(ESKF_X_PRIO) && ESKF_X_PRIO >= 2
-    __builtin_amdgcn_s_setprio(2);          // ... and let a finished one leave
-#endif
     if constexpr (LPI == 32 && ESKF_PACKED_IMAGE) {
         // 32 lanes per instance: the rows go into LDS in the ORDER OF THE PACKED RECORD (row h starts at word 25 h or
         // 26 (23 - h) + 1 and holds its elements 0..h), so the record leaves as a straight copy -- one 16-byte LDS read
@@ -3886,11 +3832,6 @@ __global__ __launch_bounds__(512, 4) void eskf_run_kernel(StepArgs a0, DevParams
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     [[maybe_unused]] const int lane = (int)threadIdx.x & 63;      // (the stamps of the diagnostic build)
     const int n_steps = ra0.n_steps;
-    // (experiment, DVI_ESKF_RUN_STAGGER=<us>: every other group of 256 blocks starts late, so that the two blocks of a CU
-    //  are not in their pre phases at the same time)
-    if (ra0.pad > 0 && (((int)blockIdx.x >> 8) & 1)) {
-        for (int i = 0; i < ra0.pad; ++i) __builtin_amdgcn_s_sleep(37);     // 37 x 64 clocks ~ 1 us
-    }
 #pragma unroll 1
     for (int k = 0; k < n_steps; ++k) {
         // (the lane index opaque per step: the LDS addresses of the hand-over and of the error-state area are formed again
@@ -4368,9 +4309,7 @@ template <typename T>
 static hipError_t launch_run_typed(int lpi, const StepArgs& a, const RunArgs& ra, const DevParams<T>& prm, hipStream_t stream) {
     const int ni = run_kernel_block_typed<T>(lpi, a, prm);
     if (!ni || ra.n_steps < 1) return hipErrorInvalidValue;
-    static const int stagger = []() { const char* e = getenv("DVI_ESKF_RUN_STAGGER"); return e ? atoi(e) : 0; }();
-    RunArgs ra_l = ra;
-    ra_l.pad = stagger;
+    const RunArgs& ra_l = ra;
     const size_t lds = (size_t)8 * 2 * (a.noise ? 664 : 600) * sizeof(T);
     const unsigned blocks = (unsigned)((a.B + ni - 1) / ni);
     static const bool verbose = []() { const char* e = getenv("DVI_ESKF_VERBOSE"); return e && e[0] == '1'; }();
@@ -4415,11 +4354,7 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
     const size_t stage_bytes = (size_t)64 * ((prm.jfull ? JB_FULL : JB_CORE) + 9) * sizeof(T);    // + parked measurement
     if (a.n_pred == 1 && !g_pre_legacy) {
         if (a.sub_count) return hipErrorInvalidValue;      // (eskf_pre4_kernel covers the whole batch)
-#ifdef ESKF_X_PRE4_LDS      // experiment: a larger LDS request = fewer blocks per CU = more, shorter generations
-        const size_t stage4 = ESKF_X_PRE4_LDS;
-#else
         const size_t stage4 = (size_t)64 * (prm.jfull ? J_FULL : J_CORE) * sizeof(T);
-#endif
         hipLaunchKernelGGL((eskf_pre4_kernel<T>), dim3((unsigned)((a.B + 63) / 64)), dim3(256), stage4, stream, a, prm);
     } else if (a.n_pred == 1) {
         if (a.sub_count) return hipErrorInvalidValue;      // (the two-role kernel covers the whole batch)
@@ -4462,12 +4397,8 @@ static hipError_t launch_step_typed(int lpi, const StepArgs& a, const DevParams<
         case 1:  // DVI_ESKF_LANES_ROWS; the gain matrix is only formed by the LDS-image kernel
             e = a.K_out ? launch_cov_t<T, 32>(a, prm, stream) : launch_cov_rows<T>(a, prm, stream);
             break;
-        case 64: e = launch_cov_t<T, 64>(a, prm, stream); break;
-        case 32: e = launch_cov_t<T, 32>(a, prm, stream); break;
-        case 24: e = launch_cov_t<T, 24>(a, prm, stream); break;
-        case 16: e = launch_cov_t<T, 16>(a, prm, stream); break;
-        case 12: e = launch_cov_t<T, 12>(a, prm, stream); break;
-        case 8:  e = launch_cov_t<T, 8>(a, prm, stream); break;
+        case 32: e = launch_cov_t<T, 32>(a, prm, stream); break;    // the LDS-image kernel (the other lane counts it was
+                                                                     // written for -- 64, 24, 16, 12, 8 -- lost to this one and are gone)
         default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;

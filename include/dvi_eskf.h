@@ -326,8 +326,8 @@ int dvi_eskf_randn(int kind, int device, uint64_t seed, int64_t first_instance, 
 /* Covariance kernel selector (for experiments and cross-checks).
  * DVI_ESKF_LANES_ROWS (default): row-resident kernel -- lane i of an instance keeps row i of P in
  * registers, 32 lanes per instance, two instances per wavefront.
- * 64 / 32 / 24 / 16 / 12 / 8: LDS-image kernel with that many lanes per instance (64 = one
- * wavefront per instance).  All variants compute the same step; they differ in rounding only. */
+ * 32: LDS-image kernel, 32 lanes per instance (the kernel that also forms the gain matrix; requests with a gain
+ * output run through it whatever is selected).  All variants compute the same step; they differ in rounding only. */
 #define DVI_ESKF_LANES_ROWS 1
 #define DVI_ESKF_LANES_ROWS24 2   /* row-resident kernel, 24 lanes per instance: eight instances per block of three wavefronts */
 int dvi_eskf_set_lanes_per_instance(dvi_eskf* h, int lanes);

@@ -349,27 +349,6 @@ def test_per_instance_inputs_match_broadcast():
         assert torch.equal(a[key], b[key]), key
 
 
-@pytest.mark.parametrize("lpi", [64, 24, 16, 12, 8])
-def test_lane_layout_variants_agree(lpi):
-    """The lanes-per-instance layouts run the same arithmetic per element."""
-    B = 23   # ragged: not a multiple of any instances-per-wave count
-    cfg, ri, Q, R, sa, so = default_run(golden_compat=False, fast=True, frozen=(0,) * 6)
-    x0 = _perturbed_x0(ri, B)
-    fa = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=32)
-    fb = _make(cfg, ri, Q, R, sa, so, B, False, x0, lpi=lpi)
-    ip = 0
-    for k in range(2):
-        for _ in range(ri.n_pred[k]):
-            fa.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
-            fb.predict(ri.dt[ip], ri.om[ip], ri.acc[ip])
-            ip += 1
-        fa.update(ri.pos[k], ri.quat[k], ri.notch[k])
-        fb.update(ri.pos[k], ri.quat[k], ri.notch[k])
-    a, b = fa.get_state(), fb.get_state()
-    for key in a:
-        assert torch.equal(a[key], b[key]), key
-
-
 @pytest.mark.parametrize("B", [1, 8, 23])
 def test_row_resident_lane_layouts_are_bitwise_identical(B):
     """Selector 2 = the row-resident kernel with 24 lanes per instance (eight instances per block of three
