@@ -3049,6 +3049,10 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     T* sC = smem + grp * REGION + R_C;
     T* sJ = smem + grp * REGION + R_J;
     T* sR = smem + grp * REGION + R_RES;
+    // (WAVE without per-instance noise: REGION is the 600-word image alone, sC / sR then point PAST the instance's region --
+    // into the neighbour's resident covariance, or past the block's allocation.  Every use of them sits in a branch that the
+    // DPP paths replace; the static_asserts next to DPPJ / DPPU / DPPR keep it that way.)
+    constexpr bool NO_C_RES = WAVE && !PIN;
     const T* sN = sR + 8;                   // PIN: diag(Q) 13 | diag(R) 7 | sigma_om 3 | pad
     // last word of the record in use (dt without the gyro block of Q, else the end of N6) and its LDS slot
     const int jlast = prm.q_gyro ? J_FULL - 1 : J_CORE - 1;
@@ -3102,6 +3106,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     // handed to the Fx applications as DPP operands (JRegs); it is copied to LDS only for the gyro
     // block of Q (tune mode), whose N6 rows noise_rows() reads from there
     constexpr bool DPPJ = LPI == 32;
+    static_assert(DPPJ || !NO_C_RES, "the residual words sR lie outside the LDS region of this build");
     JRegs<T> Jr;
 #define ESKF_STAGE_J(SRC, RES)                                                                     \
     {                                                                                              \
@@ -3363,6 +3368,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
     const bool do_update_run = a.do_update != 0;
     if (do_update_run) {
         constexpr bool DPPU = LPI == 32;
+        static_assert(DPPU || !NO_C_RES, "the residual words sR lie outside the LDS region of this build");
         if constexpr (DPPU) status = (dpp_bcast<7>(Xres) != T(0)) ? DVI_STATUS_NONFINITE : 0;
         else status = (sR[7] != T(0)) ? DVI_STATUS_NONFINITE : 0;
         T E[7];                             // error estimate at the measured components (group-uniform)
@@ -3483,6 +3489,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         const bool upd = !fail;
         if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) e = T(0);   // Filter.py:377-379
         constexpr bool DPPR = LPI == 32;    // the six attitude components of the error state reach every lane as DPP operands
+        static_assert(DPPR || !NO_C_RES, "the error-state words sC lie outside the LDS region of this build");
         if (upd && active) {
             if constexpr (!DPPR) sC[row] = e;
             if (valid && !(WAVE && e_keep)) {
