@@ -46,10 +46,11 @@ struct dvi_eskf {
                         // state behind the host's back, so from then on the hint is always "maybe"
     void* d_noise;      // nullable [B][NOISE_WORDS]: per-instance diag(Q) | diag(R) | sigma_om
     int jac_ip;         // record of the last predict in d_J when it was written in full (keep_jac), else -1
-    // dvi_eskf_run_epochs on an under-filled batch: the two halves of the batch run their epochs on two streams of the
-    // handle's own, forked from and joined to the caller's stream by events (created at first use)
-    hipStream_t side[2];
-    hipEvent_t ev_fork, ev_join[2];
+    // dvi_eskf_run_epochs on an under-filled batch: parts of the batch (two to MAX_SIDE) run their epochs on as many streams
+    // of the handle's own, forked from and joined to the caller's stream by events (created at first use)
+    static constexpr int MAX_SIDE = 8;
+    hipStream_t side[MAX_SIDE];
+    hipEvent_t ev_fork, ev_join[MAX_SIDE];
     bool side_ready;
     // dvi_eskf_run_epochs through the long-horizon kernel: the schedule's predict counts on the device
     int32_t* d_npred;
@@ -68,14 +69,14 @@ size_t elem_size(int dtype) { return dtype == DVI_ESKF_F64 ? sizeof(double) : si
 
 void free_side_streams(dvi_eskf* h) {
     if (!h->side_ready) return;
-    for (int i = 0; i < 2; ++i) { (void)hipStreamDestroy(h->side[i]); (void)hipEventDestroy(h->ev_join[i]); }
+    for (int i = 0; i < dvi_eskf::MAX_SIDE; ++i) { (void)hipStreamDestroy(h->side[i]); (void)hipEventDestroy(h->ev_join[i]); }
     (void)hipEventDestroy(h->ev_fork);
     h->side_ready = false;
 }
 bool ensure_side_streams(dvi_eskf* h) {
     if (h->side_ready) return true;
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i)
+    for (int i = 0; i < dvi_eskf::MAX_SIDE && ok; ++i)
         ok = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     h->side_ready = ok;     // (a partial failure leaks a handle or two of a process that is out of resources anyway)
@@ -751,34 +752,40 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
     const char* pos = static_cast<const char*>(sc->pos);
     const char* quat = static_cast<const char*>(sc->quat_xyzw);
     const char* notch = static_cast<const char*>(sc->notch);
-    // An under-filled batch (the serial part of an epoch -- its recurrences -- leaves most of the chip idle): the two
-    // halves of the batch run their epochs on two streams, so that one half's recurrences and Jacobian kernel run
-    // next to the other half's covariance kernel.  Instances do not interact, the kernels of a half touch that half's
-    // records only: the results are the same bits.  (DVI_ESKF_EPOCH_STREAMS=0 switches it off.)
-    static const bool two_streams = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS"); return !(e && e[0] == '0'); }();
+    // An under-filled batch (the serial part of an epoch -- its recurrences -- leaves most of the chip idle): parts of the
+    // batch run their epochs on streams of their own, so that one part's recurrences and Jacobian kernel run next to the
+    // other parts' covariance kernels.  Instances do not interact, the kernels of a part touch that part's records only:
+    // the results are the same bits.  DVI_ESKF_EPOCH_STREAMS=0 switches it off, =k (2..8) asks for k parts; two by default.
+    // (Measured, config #5's schedule, us per camera frame fp32 / fp64 at B = 8 192 and 16 384: two parts 106 / 147 and 167 / 244,
+    //  three 106 / 145 and 167 / 237, four 162 / 216 and 223 / 310, eight 241 / 284 and 270 / 370 -- from four parts on the
+    //  enqueue, three launches per part and frame from one host thread, is what a frame waits for.)
+    static const int streams_env = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS"); return e ? atoi(e) : -1; }();
     static const int64_t two_streams_max = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS_MAX"); return e ? (int64_t)atoll(e) : (int64_t)16384; }();
     // (measured, config #5's schedule, us per camera frame, one stream -> two: B = 1 024 72 -> 75 fp32 / 80 -> 82 fp64; 2 048
     //  78 -> 79 / 98 -> 86; 4 096 100 -> 83 / 115 -> 106; 8 192 129 -> 114 / 148 -> 146; 16 384 184 -> 167 / 256 -> 246)
     static const int64_t two_streams_min = []() { const char* e = getenv("DVI_ESKF_EPOCH_STREAMS_MIN"); return e ? (int64_t)atoll(e) : (int64_t)2048; }();
     int shortest = 0x7fffffff;
     for (int64_t e = 0; e < sc->n_epochs; ++e) shortest = sc->n_pred[e] < shortest ? sc->n_pred[e] : shortest;
-    // (whether the kernels can run a half of the batch: asked where the launcher decides it, eskf_kernels.hip)
-    const bool split = !src && two_streams && !sc->rows_out && (h->B % 128) == 0 && h->B >= two_streams_min && h->B <= two_streams_max &&
+    int n_parts = streams_env >= 0 ? streams_env : 2;
+    if (n_parts > dvi_eskf::MAX_SIDE) n_parts = dvi_eskf::MAX_SIDE;
+    while (n_parts > 1 && (h->B % (64 * n_parts)) != 0) --n_parts;       // (parts are multiples of a wavefront of instances)
+    const int64_t part = n_parts > 1 ? h->B / n_parts : 0;
+    // (whether the kernels can run a part of the batch: asked where the launcher decides it, eskf_kernels.hip)
+    const bool split = !src && n_parts > 1 && !sc->rows_out && h->B >= two_streams_min && h->B <= two_streams_max &&
                        sc->n_epochs >= 2 &&
-                       eskf::epoch_sub_batches_ok(h->lpi, h->B / 2, h->B / 2, shortest, h->d_noise != nullptr, false, h->d_aux != nullptr);
+                       eskf::epoch_sub_batches_ok(h->lpi, part, part, shortest, h->d_noise != nullptr, false, h->d_aux != nullptr);
     if (split) {
         DeviceGuard g(h->device);
         hipStream_t cs = (hipStream_t)stream;
         if (!g.ok || !ensure_side_streams(h)) return DVI_ESKF_EHIP;
         if (hipEventRecord(h->ev_fork, cs) != hipSuccess) return DVI_ESKF_EHIP;     // (nothing forked yet: nothing to join)
-        const int64_t half = h->B / 2;
         // From here on EVERY exit goes through the join below: a side stream that has been made to wait for the fork
         // event holds work that is unordered with respect to `stream` (and, under capture, belongs to the capture: an
         // unjoined stream makes hipStreamEndCapture fail) until `stream` waits for its join event.  The first error is
         // what the call returns.
         int rc_first = DVI_ESKF_OK;
-        bool forked[2] = {false, false};
-        for (int s2 = 0; s2 < 2 && rc_first == DVI_ESKF_OK; ++s2) {
+        bool forked[dvi_eskf::MAX_SIDE] = {};
+        for (int s2 = 0; s2 < n_parts && rc_first == DVI_ESKF_OK; ++s2) {
             if (hipStreamWaitEvent(h->side[s2], h->ev_fork, 0) != hipSuccess) rc_first = DVI_ESKF_EHIP;
             else forked[s2] = true;
         }
@@ -789,18 +796,18 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
         const int64_t fail_epoch = -1;
 #endif
         size_t off2 = 0;
-        for (int64_t e = 0; e < sc->n_epochs && rc_first == DVI_ESKF_OK; ++e) {     // (enqueued epoch by epoch, alternating: both queues always have work)
+        for (int64_t e = 0; e < sc->n_epochs && rc_first == DVI_ESKF_OK; ++e) {     // (enqueued epoch by epoch, in turn: every queue always has work)
             const int n = sc->n_pred[e];
-            for (int s2 = 0; s2 < 2 && rc_first == DVI_ESKF_OK; ++s2) {
+            for (int s2 = 0; s2 < n_parts && rc_first == DVI_ESKF_OK; ++s2) {
                 if (e == fail_epoch && s2 == 1) { rc_first = DVI_ESKF_EHIP; break; }
                 rc_first = step_common(h, n, 1, dt + off2 * dt_row, sc->dt_per_instance, om + off2 * imu_row, acc + off2 * imu_row,
                                        sc->imu_per_instance, pos + (size_t)e * mrow * 3 * es, quat + (size_t)e * mrow * 4 * es,
                                        notch + (size_t)e * mrow * es, sc->meas_per_instance, nullptr,
-                                       sc->status ? sc->status + (size_t)e * B : nullptr, h->side[s2], nullptr, s2 * half, half);
+                                       sc->status ? sc->status + (size_t)e * B : nullptr, h->side[s2], nullptr, s2 * part, part);
             }
             off2 += (size_t)n;
         }
-        for (int s2 = 0; s2 < 2; ++s2) {
+        for (int s2 = 0; s2 < n_parts; ++s2) {
             if (!forked[s2]) continue;
             if (hipEventRecord(h->ev_join[s2], h->side[s2]) != hipSuccess || hipStreamWaitEvent(cs, h->ev_join[s2], 0) != hipSuccess) {
                 if (rc_first == DVI_ESKF_OK) rc_first = DVI_ESKF_EHIP;

@@ -1,7 +1,7 @@
 // eskf_epochs.hip -- the long-horizon kernel: a whole run of epochs (N IMU samples, then one camera update; the time loop
 // of Filter.run / run_one_epoch / propagate_imu, dvi_ekf/filter/Filter.py:144-217) in ONE launch, for any N >= 0.
 //
-// A block owns NI = 2 NC filter instances for the whole run.  Its wavefronts split the work of the reference's
+// A block owns NI = 2 NC filter instances (fp32 also 4 NC: two pairs per covariance wavefront, Lay::PP) for the whole run.  Its wavefronts split the work of the reference's
 // Filter.propagate (Filter.py:219-230) and Filter.update (351-395) the way the data depend on each other:
 //
 //   RA   (wavefront 0, lane = instance)  the recurrence of _predict_nominal that carries attitude, position, velocity
@@ -57,14 +57,19 @@ constexpr int F_LOADED = 8;              // [NC] records consumer wavefront w ha
 constexpr int F_CEPOCH = 24;             // [NC] epochs whose update wavefront w has finished (error state in the mailbox)
 constexpr int NFLAGS = 40;
 
-template <typename T, int NC>
+// NC covariance wavefronts, each with PP pairs of instances (PP = 2: fp32 only -- two rows of 24 words per lane; the
+// producers then serve 4 NC instances, with twice the lanes of their wavefronts at work)
+template <typename T, int NC_, int PP_ = 1>
 struct Lay {
-    static constexpr int NI = 2 * NC;
-    static constexpr int NIP = NI <= 4 ? 4 : NI <= 8 ? 8 : NI <= 16 ? 16 : 32;     // lanes per predict in the J wavefronts
+    static constexpr int NC = NC_, PP = PP_;
+    static constexpr int NI = 2 * NC * PP;
+    static constexpr int NIP = NI <= 4 ? 4 : NI <= 8 ? 8 : NI <= 16 ? 16 : NI <= 32 ? 32 : 64;     // lanes per predict in the J wavefronts
     static constexpr int PPP = 64 / NIP < 4 ? 64 / NIP : 4;                        // predicts per J pass
-    // ring depths: what fits next to the images (fp64, NC = 12: 115 KB of images)
-    static constexpr int D = NC > 10 ? (sizeof(T) == 8 ? 2 : 4) : NC > 8 ? 4 : NC > 4 ? (sizeof(T) == 8 ? 4 : 6) : 8;      // records
-    static constexpr int DA = NC > 10 ? (sizeof(T) == 8 ? 2 : 4) : NC > 8 ? 4 : 8;                  // aux entries
+    // ring depths: what fits next to the images (24 instances in fp64, 48 in fp32: 115 KB of images)
+    static constexpr int D = PP > 1 ? (NC > 10 ? 2 : NC > 8 ? 4 : 6)                                                        // records
+                                    : NC > 10 ? (sizeof(T) == 8 ? 2 : 4) : NC > 8 ? 4 : NC > 4 ? (sizeof(T) == 8 ? 4 : 6) : 8;
+    static constexpr int DA = PP > 1 ? (NC > 10 ? 2 : NC > 8 ? 4 : 8) : NC > 10 ? (sizeof(T) == 8 ? 2 : 4) : NC > 8 ? 4 : 8;    // aux entries
+    static_assert(NI <= 64 && (PP == 1 || sizeof(T) == 4), "lane = instance in the recurrences; two pairs per wavefront in fp32 only");
     static constexpr int O_IMG = 0;
     static constexpr int O_RING = O_IMG + NI * IMG;
     static constexpr int O_AUX = O_RING + D * NI * RW;
@@ -172,10 +177,9 @@ __device__ __forceinline__ Pending<T> pending_of(const StepArgs& a, int e, int64
 }
 
 // ---- RA: position, velocity, attitude (the arithmetic of eskf_nominal_kernel, role 0) ----------------------------
-template <typename T, int NC>
+template <typename T, typename L>
 __device__ __forceinline__ void role_ra(const EpochsArgs& A, const DevParams<T>& prm, T* lds, const int lane, const int64_t b0, const int ni,
                                         const int nca, unsigned long long* wait_cycles) {
-    using L = Lay<T, NC>;
     constexpr int NI = L::NI;
     if (lane >= NI) return;
     const StepArgs& a = A.a;
@@ -348,10 +352,9 @@ __device__ __forceinline__ void role_ra(const EpochsArgs& A, const DevParams<T>&
 }
 
 // ---- RB: camera attitude, notch states, residual (eskf_nominal_kernel, role 1) ----------------------------------
-template <typename T, int NC>
+template <typename T, typename L>
 __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>& prm, T* lds, const int lane, const int64_t b0, const int ni,
                                         const int nca, unsigned long long* wait_cycles) {
-    using L = Lay<T, NC>;
     constexpr int NI = L::NI;
     if (lane >= NI) return;
     const StepArgs& a = A.a;
@@ -522,10 +525,9 @@ __device__ __forceinline__ void role_rb(const EpochsArgs& A, const DevParams<T>&
 }
 
 // ---- JA / JB: the Jacobian blocks of up to PPP predicts at once (eskf_jac_kernel's arithmetic) --------------------
-template <typename T, int NC, int WHICH>
+template <typename T, typename L, int WHICH>
 __device__ __forceinline__ void role_j(const EpochsArgs& A, const DevParams<T>& prm, T* lds, const int lane, const int nca,
                                        unsigned long long* wait_cycles) {
-    using L = Lay<T, NC>;
     constexpr int NI = L::NI, NIP = L::NIP, PPP = L::PPP, D = L::D, DA = L::DA;
     const T* aux = lds + L::O_AUX;
     T* ring = lds + L::O_RING;
@@ -635,15 +637,15 @@ __device__ __forceinline__ void noise_diag_exec(const DevParams<float>& prm, flo
 #undef EP_NQ
 }
 
-// ---- C: the covariance of two instances, rows in registers for the whole run -------------------------------------
+// ---- C: the covariance of PP pairs of instances, rows in registers for the whole run -----------------------------
 // (the 32-lanes-per-instance / DPP / SLIM path of cov_rows_body, cut at its phase boundaries: load | predict | update +
-//  reset | store -- same statements in the same order)
-template <typename T, int NC>
+//  reset | store -- same statements in the same order.  PP = 2: the wavefront does every phase for its first pair, then
+//  for its second -- two independent instruction streams between the same synchronisation points)
+template <typename T, typename L>
 __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& prm, T* lds, const int cw, const int lane_in, const int64_t b0,
                                        const int ni, unsigned long long* wait_cycles) {
-    using L = Lay<T, NC>;
     using namespace rowk;
-    constexpr int NI = L::NI, D = L::D;
+    constexpr int NI = L::NI, D = L::D, PP = L::PP;
     constexpr int PW = 16 / (int)sizeof(T);         // words per 16-byte piece of the packed record
     constexpr int NPC = 300 / PW;                   // pieces per record
     constexpr int NV = (NPC + 31) / 32;             // pieces per lane
@@ -654,23 +656,31 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
     const int grp = lane >> 5, lig = lane & 31;
     const bool active = lig < 24;
     int row = active ? lig : 23;                    // (idle lanes shadow row 23 and write nothing)
-    T* sB = lds + L::O_IMG + (cw * 2 + grp) * IMG;
     const T* ring = lds + L::O_RING;
-    T* mbx = lds + L::O_MBOX;
     int* flags = reinterpret_cast<int*>(lds + L::O_FLAGS);
-    const int il = cw * 2 + grp;                    // the instance's number in the block
-    const bool valid = il < ni;
-    const int ilc = valid ? il : ni - 1;            // (an odd block's last lanes recompute its last instance, write nothing)
-    const int64_t inst = b0 + ilc;
-    T* mb = mbx + ilc * MW;
+    T* sB[PP];                                      // the pair's exchange images
+    T* mb[PP];
+    bool valid[PP];
+    int ilc[PP];
+    int64_t inst[PP];
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int il = (cw * PP + pp) * 2 + grp;    // the instance's number in the block
+        valid[pp] = il < ni;
+        ilc[pp] = valid[pp] ? il : ni - 1;          // (a ragged block's last lanes recompute its last instance, write nothing)
+        inst[pp] = b0 + ilc[pp];
+        sB[pp] = lds + L::O_IMG + il * IMG;
+        mb[pp] = lds + L::O_MBOX + ilc[pp] * MW;
+    }
     asm volatile("" : "+v"(row));
     constexpr int sel[7] = {18, 19, 20, 21, 22, 23, 15};
-    T p[24];                                        // row `row` of P
+    T p[PP][24];                                    // row `row` of P, per pair
     // ---- load: packed record -> LDS image in its own order -> the lane's row (cov_rows_body, ESKF_ROWS_VIA_LDS)
-    {
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
         typedef T row_piece_t __attribute__((ext_vector_type(PW)));
         row_piece_t pv_[NV];
-        const char* gPb_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.P_src) + inst * 300);
+        const char* gPb_ = reinterpret_cast<const char*>(reinterpret_cast<const T*>(a.P_src) + inst[pp] * 300);
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e_ = lig + k * 32;
@@ -679,14 +689,14 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int e_ = lig + k * 32;
-            *reinterpret_cast<row_piece_t*>(sB + PW * (e_ < NPC ? e_ : NPC - 1)) = pv_[k];
+            *reinterpret_cast<row_piece_t*>(sB[pp] + PW * (e_ < NPC ? e_ : NPC - 1)) = pv_[k];
         }
         wave_sync();
         const unsigned rw_ = (unsigned)row;
-        const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sB;
+        const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sB[pp];
         constexpr unsigned ESZ = (unsigned)sizeof(T);
         const unsigned va_ = lb_ + ESZ * (rw_ < 12u ? 25u * rw_ : 26u * (23u - rw_) + 1u), vb_ = lb_ + ESZ * rw_;
-        gather_row_masked(va_, vb_, p);
+        gather_row_masked(va_, vb_, p[pp]);
         wave_sync();
     }
     int g = 0;
@@ -697,21 +707,26 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
         // counters are read first: LDS executes a wavefront's reads in order, so a record read behind counters that say
         // "complete" is the complete record), requested while the predict before is still computing its second Fx
         // application; only a record that was not ready then is asked for again, polling.
-        T jn[3] = {T(0), T(0), T(0)};
+        T jn[PP][3];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) jn[pp][0] = jn[pp][1] = jn[pp][2] = T(0);
         int fa = 0, fb = 0;
         auto fetch_record = [&](int gg) {
             typedef const volatile __attribute__((address_space(3))) T lds_word_t;
             typedef const volatile __attribute__((address_space(3))) int lds_flag_t;
-            const T* rec = ring + ((gg % D) * NI + ilc) * RW;
             const int w0 = lig >= J_B0 ? lig - J_B0 : 0;
             const int w2 = lig + 64 - J_B0 < RW - 1 ? lig + 64 - J_B0 : RW - 1;
             fa = *(lds_flag_t*)(flags + F_JA);
             fb = *(lds_flag_t*)(flags + F_JB);
             // lane l holds words l, 32 + l, 64 + l of the 75-word record of the two-kernel path, whose words 0..7 are the
             // residual; the ring keeps the 67 block words
-            jn[0] = *(lds_word_t*)(rec + w0);
-            jn[1] = *(lds_word_t*)(rec + (32 + lig - J_B0));
-            jn[2] = *(lds_word_t*)(rec + w2);
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                const T* rec = ring + ((gg % D) * NI + ilc[pp]) * RW;
+                jn[pp][0] = *(lds_word_t*)(rec + w0);
+                jn[pp][1] = *(lds_word_t*)(rec + (32 + lig - J_B0));
+                jn[pp][2] = *(lds_word_t*)(rec + w2);
+            }
         };
         auto record_ready = [&](int gg) {
             return __builtin_amdgcn_readfirstlane(fa) > gg && __builtin_amdgcn_readfirstlane(fb) > gg;
@@ -724,17 +739,27 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
                 fetch_record(g);
             }
             EP_WAIT_END(0)
-            T j0[3] = {jn[0], jn[1], jn[2]};
-            asm volatile("" : "+v"(j0[0]), "+v"(j0[1]), "+v"(j0[2]) : : "memory");
-            if (lane == 0) publish(flags + F_LOADED + cw, g + 1);
-            JRegs<T> Jr;
+            T j0[PP][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) spread_rows(j0[q], Jr.X[q], Jr.Y[q]);
-            fx_apply_store_dpp(Jr, p, sB + row * PS, active);      // column `row` of Fx P = row `row` of W = P Fx^T
+            for (int pp = 0; pp < PP; ++pp) {
+                j0[pp][0] = jn[pp][0]; j0[pp][1] = jn[pp][1]; j0[pp][2] = jn[pp][2];
+                asm volatile("" : "+v"(j0[pp][0]), "+v"(j0[pp][1]), "+v"(j0[pp][2]) : : "memory");
+            }
+            if (lane == 0) publish(flags + F_LOADED + cw, g + 1);
+            JRegs<T> Jr[PP];
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) spread_rows(j0[pp][q], Jr[pp].X[q], Jr[pp].Y[q]);
+                fx_apply_store_dpp(Jr[pp], p[pp], sB[pp] + row * PS, active);  // column `row` of Fx P = row `row` of W = P Fx^T
+            }
             wave_sync();
             if (k + 1 < n) fetch_record(g + 1);
-            fx_apply_col_dpp(Jr, sB + row, p);                     // column `row` of Fx P Fx^T = row `row` of P'
-            noise_diag_exec(prm, p);
+#pragma unroll
+            for (int pp = 0; pp < PP; ++pp) {
+                fx_apply_col_dpp(Jr[pp], sB[pp] + row, p[pp]);                 // column `row` of Fx P Fx^T = row `row` of P'
+                noise_diag_exec(prm, p[pp]);
+            }
             wave_sync();
         }
         // ================================ update ===========================================
@@ -743,91 +768,103 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
         EP_WAIT_BEGIN()
         wait_ge(flags + F_RB_EP, e + 1);
         EP_WAIT_END(1)
-        T Xres = mb[MB_RES + (lig & 7)];            // lanes 0..7 of each 16-lane row: the residual and its flag
-        asm("s_nop 1" : "+v"(Xres));
-        T ee = T(0);                                // component `row` of the error state
-        int status = 0;
-        bool fail = false;
-        {
-            status = (dpp_bcast<7>(Xres) != T(0)) ? DVI_STATUS_NONFINITE : 0;
-            T E[7];
-            int napplied = 0;
-            unsigned long long okm[7] = {0, 0, 0, 0, 0, 0, 0};
-            unsigned long long failm = 0;
-            constexpr int CS = 32;
-            static_for<0, 7>([&](auto M) {
-                constexpr int m = decltype(M)::value;
-                constexpr int sm = sel[m];
-                const T pm = p[sm];
-                lds_store1(sB + m * CS + lig, pm);
-                T X, Y;                     // column sel_m of the current P: X rows 0..15, Y rows 16..23
-                spread_rows(pm, X, Y);
-                const T csel = dpp_bcast<(sm & 15)>(sm < 16 ? X : Y);
-                const T sv = csel + prm.r[m];
-                failm |= unusable_pivot_mask(sv);
-                okm[m] = ~failm;
-                if (!__builtin_amdgcn_inverse_ballot_w64(failm)) {
-                    const T gg = fast_rcp(sv);
-                    const T rm = dpp_bcast<m>(Xres);
-                    const T tau = (m == 0) ? rm * gg : (rm - E[m]) * gg;
-                    const T nkk = pm * -gg;
-                    if constexpr (m == 0) ee = pm * tau;
-                    else ee += pm * tau;
-                    static_for<m + 1, 7>([&](auto M2) {
-                        constexpr int s2 = sel[decltype(M2)::value];
-                        dpp_fmac<(s2 & 15), m == 0>(E[decltype(M2)::value], s2 < 16 ? X : Y, tau);
-                    });
-                    static_for<12, 24>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        dpp_fmac<(j & 15)>(p[j], j < 16 ? X : Y, nkk);
-                    });
-                    static_for<0, 12>([&](auto J) {
-                        constexpr int j = decltype(J)::value;
-                        dpp_fmac<(j & 15)>(p[j], X, nkk);
-                    });
-                }
-                pin_row(p);
-                asm volatile("" : "+v"(ee), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
-            });
-            fail = __builtin_amdgcn_inverse_ballot_w64(failm);
-            if (__builtin_expect(fail, 0)) wave_sync();
-            if (__builtin_expect(fail, 0)) {
-                status |= DVI_STATUS_SINGULAR;
+        const bool last = e + 1 == A.n_epochs;
+        T eev[PP];                                  // component `row` of the error state, per pair
+        bool updv[PP];
+        static_for<0, PP>([&](auto PPc) {
+            constexpr int pp = decltype(PPc)::value;
+            T (&pr)[24] = p[pp];
+            T* const sBp = sB[pp];
+            T Xres = mb[pp][MB_RES + (lig & 7)];    // lanes 0..7 of each 16-lane row: the residual and its flag
+            asm("s_nop 1" : "+v"(Xres));
+            T ee = T(0);
+            int status = 0;
+            bool fail = false;
+            {
+                status = (dpp_bcast<7>(Xres) != T(0)) ? DVI_STATUS_NONFINITE : 0;
+                T E[7];
+                int napplied = 0;
+                unsigned long long okm[7] = {0, 0, 0, 0, 0, 0, 0};
+                unsigned long long failm = 0;
+                constexpr int CS = 32;
+                static_for<0, 7>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
+                    constexpr int sm = sel[m];
+                    const T pm = pr[sm];
+                    lds_store1(sBp + m * CS + lig, pm);
+                    T X, Y;                     // column sel_m of the current P: X rows 0..15, Y rows 16..23
+                    spread_rows(pm, X, Y);
+                    const T csel = dpp_bcast<(sm & 15)>(sm < 16 ? X : Y);
+                    const T sv = csel + prm.r[m];
+                    failm |= unusable_pivot_mask(sv);
+                    okm[m] = ~failm;
+                    if (!__builtin_amdgcn_inverse_ballot_w64(failm)) {
+                        const T gg = fast_rcp(sv);
+                        const T rm = dpp_bcast<m>(Xres);
+                        const T tau = (m == 0) ? rm * gg : (rm - E[m]) * gg;
+                        const T nkk = pm * -gg;
+                        if constexpr (m == 0) ee = pm * tau;
+                        else ee += pm * tau;
+                        static_for<m + 1, 7>([&](auto M2) {
+                            constexpr int s2 = sel[decltype(M2)::value];
+                            dpp_fmac<(s2 & 15), m == 0>(E[decltype(M2)::value], s2 < 16 ? X : Y, tau);
+                        });
+                        static_for<12, 24>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            dpp_fmac<(j & 15)>(pr[j], j < 16 ? X : Y, nkk);
+                        });
+                        static_for<0, 12>([&](auto J) {
+                            constexpr int j = decltype(J)::value;
+                            dpp_fmac<(j & 15)>(pr[j], X, nkk);
+                        });
+                    }
+                    pin_row(pr);
+                    asm volatile("" : "+v"(ee), "+v"(E[0]), "+v"(E[1]), "+v"(E[2]), "+v"(E[3]), "+v"(E[4]), "+v"(E[5]), "+v"(E[6]));
+                });
+                fail = __builtin_amdgcn_inverse_ballot_w64(failm);
+                if (__builtin_expect(fail, 0)) wave_sync();
+                if (__builtin_expect(fail, 0)) {
+                    status |= DVI_STATUS_SINGULAR;
 #pragma unroll
-                for (int m = 0; m < 7; ++m) napplied += (int)((okm[m] >> lane) & 1ull);
+                    for (int m = 0; m < 7; ++m) napplied += (int)((okm[m] >> lane) & 1ull);
 #pragma unroll
-                for (int m = 6; m >= 0; --m) {
-                    if (m < napplied) {
-                        const T* cb = sB + m * CS;
-                        const T gg = fast_rcp(cb[sel[m]] + prm.r[m]);
-                        const T kk = cb[row] * gg;
+                    for (int m = 6; m >= 0; --m) {
+                        if (m < napplied) {
+                            const T* cb = sBp + m * CS;
+                            const T gg = fast_rcp(cb[sel[m]] + prm.r[m]);
+                            const T kk = cb[row] * gg;
 #pragma unroll
-                        for (int j = 0; j < 24; ++j) p[j] += kk * cb[j];
-                        pin_row(p);
+                            for (int j = 0; j < 24; ++j) pr[j] += kk * cb[j];
+                            pin_row(pr);
+                        }
                     }
                 }
             }
-        }
-        {
             const bool upd = !fail;
             if (row >= 9 && row < 15 && ((prm.frozen_mask >> (row - 9)) & 1)) ee = T(0);   // Filter.py:377-379
             // The error state and the status word are final here: they go to the recurrences through the mailbox BEFORE the
             // reset of the covariance, which then runs next to the injection (State.__add__) on the producer side; after the
             // run's last update they go to memory, where the next call (or dvi_eskf_flush) finds them -- what the epochs
             // enqueued one by one leave behind
-            {
-                const bool last = e + 1 == A.n_epochs;
-                if (valid) {
-                    if (lig < 24) mb[MB_E + lig] = upd ? ee : T(0);
-                    if (lig == 24) mb[MB_ST] = status_as_word(status | DVI_STATUS_PENDING, T(0));
-                    if (last && upd && active) reinterpret_cast<T*>(a.e)[inst * 24 + row] = ee;
-                    if (lig == 0) {
-                        if (last) a.status_ws[inst] = status | DVI_STATUS_PENDING;
-                        if (a.status) a.status[(int64_t)e * a.B + inst] = status;
-                    }
+            if (valid[pp]) {
+                if (lig < 24) mb[pp][MB_E + lig] = upd ? ee : T(0);
+                if (lig == 24) mb[pp][MB_ST] = status_as_word(status | DVI_STATUS_PENDING, T(0));
+                if (last && upd && active) reinterpret_cast<T*>(a.e)[inst[pp] * 24 + row] = ee;
+                if (lig == 0) {
+                    if (last) a.status_ws[inst[pp]] = status | DVI_STATUS_PENDING;
+                    if (a.status) a.status[(int64_t)e * a.B + inst[pp]] = status;
                 }
-                if (lane == 0) publish(flags + F_CEPOCH + cw, e + 1);
             }
+            eev[pp] = ee;
+            updv[pp] = upd;
+        });
+        if (lane == 0) publish(flags + F_CEPOCH + cw, e + 1);
+        static_for<0, PP>([&](auto PPc) {
+            constexpr int pp = decltype(PPc)::value;
+            T (&pr)[24] = p[pp];
+            T* const sBp = sB[pp];
+            const T ee = eev[pp];
+            const bool upd = updv[pp];
             T Gt[3], Gc[3];
             {
                 T Xe, Ye;
@@ -835,22 +872,22 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
                 Gt[0] = T(0.5) * dpp_bcast<6>(Xe); Gt[1] = T(0.5) * dpp_bcast<7>(Xe); Gt[2] = T(0.5) * dpp_bcast<8>(Xe);
                 Gc[0] = T(0.5) * dpp_bcast<5>(Ye); Gc[1] = T(0.5) * dpp_bcast<6>(Ye); Gc[2] = T(0.5) * dpp_bcast<7>(Ye);
             }
-            T* sY = sB;     // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
+            T* sY = sBp;    // [24][XS]: columns 6:9 -> words 0:3, columns 21:24 -> words 4:7
             if (upd) {
                 // ---- reset G P G^T (Filter.py:387-390), G = I - [theta/2]x on 6:9 and 21:24: column part, in registers
-                const T a0 = p[6], a1 = p[7], a2 = p[8];
-                p[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
-                p[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
-                p[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
-                const T c0 = p[21], c1 = p[22], c2 = p[23];
-                p[21] = c0 + Gc[2] * c1 - Gc[1] * c2;
-                p[22] = c1 - Gc[2] * c0 + Gc[0] * c2;
-                p[23] = c2 + Gc[1] * c0 - Gc[0] * c1;
+                const T a0 = pr[6], a1 = pr[7], a2 = pr[8];
+                pr[6] = a0 + Gt[2] * a1 - Gt[1] * a2;
+                pr[7] = a1 - Gt[2] * a0 + Gt[0] * a2;
+                pr[8] = a2 + Gt[1] * a0 - Gt[0] * a1;
+                const T c0 = pr[21], c1 = pr[22], c2 = pr[23];
+                pr[21] = c0 + Gc[2] * c1 - Gc[1] * c2;
+                pr[22] = c1 - Gc[2] * c0 + Gc[0] * c2;
+                pr[23] = c2 + Gc[1] * c0 - Gc[0] * c1;
                 if (active) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        sY[row * XS + k] = p[6 + k];
-                        sY[row * XS + 4 + k] = p[21 + k];
+                        sY[row * XS + k] = pr[6 + k];
+                        sY[row * XS + 4 + k] = pr[21 + k];
                     }
                 }
             }
@@ -871,9 +908,9 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
                     const bool jl = j >= 6 && j < 9, jh = j >= 21;
                     if (jl || jh) {
                         const int sj = jl ? j - 6 : 4 + j - 21;
-                        p[j] = k0 * lds_load1(y0 + sj) + k1 * lds_load1(y0 + XS + sj) + k2 * lds_load1(y0 + 2 * XS + sj);
+                        pr[j] = k0 * lds_load1(y0 + sj) + k1 * lds_load1(y0 + XS + sj) + k2 * lds_load1(y0 + 2 * XS + sj);
                     } else {
-                        p[j] = lds_load1(sY + j * XS + sw);
+                        pr[j] = lds_load1(sY + j * XS + sw);
                     }
                 }
             }
@@ -882,43 +919,44 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
             // stores the lower triangle and the next one reads P[i][j] = packed[max(i, j)][min(i, j)].  The rows a lane
             // computes are not symmetric to the last bit, so the same is done here between two epochs -- through the image,
             // the store phase's packed order and the load phase's gather -- or a run would depend on where it is cut into calls.
-            if (e + 1 < A.n_epochs) {
+            if (!last) {
                 const int st_ = row < 12 ? 25 * row : 26 * (23 - row) + 1;
-                T* rp_ = sB + st_;
+                T* rp_ = sBp + st_;
                 static_for<0, 24>([&](auto JJ) {
                     constexpr int j = decltype(JJ)::value;
                     constexpr unsigned long long m32 = (0x00ffffffull >> j) << j, m64 = m32 | (m32 << 32);
-                    if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[j]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, pr[j]);
                 });
                 wave_sync();
                 const unsigned rw_ = (unsigned)row;
-                const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sB;
+                const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sBp;
                 constexpr unsigned ESZ = (unsigned)sizeof(T);
                 const unsigned va_ = lb_ + ESZ * (rw_ < 12u ? 25u * rw_ : 26u * (23u - rw_) + 1u), vb_ = lb_ + ESZ * rw_;
-                gather_row_masked(va_, vb_, p);
+                gather_row_masked(va_, vb_, pr);
                 wave_sync();
             }
-        }
+        });
     }
     // ---- store: rows -> LDS in the order of the packed record -> the record as a straight copy ------------------------
-    {
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
         const int st_ = row < 12 ? 25 * row : 26 * (23 - row) + 1;
-        T* rp_ = sB + st_;
+        T* rp_ = sB[pp] + st_;
         static_for<0, 24>([&](auto JJ) {
             constexpr int j = decltype(JJ)::value;
             constexpr unsigned long long m32 = (0x00ffffffull >> j) << j, m64 = m32 | (m32 << 32);
-            if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[j]);
+            if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[pp][j]);
         });
         wave_sync();
-        if (valid) {
-            char* gPb_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.P) + inst * 300);
+        if (valid[pp]) {
+            char* gPb_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.P) + inst[pp] * 300);
             TP v[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int e_ = lig + k * 32;
                 typedef T piece_vec_t __attribute__((ext_vector_type(PW)));
                 typedef const volatile __attribute__((address_space(3))) piece_vec_t lds_piece_t;
-                const piece_vec_t t_ = *(lds_piece_t*)(sB + PW * (e_ < NPC ? e_ : NPC - 1));
+                const piece_vec_t t_ = *(lds_piece_t*)(sB[pp] + PW * (e_ < NPC ? e_ : NPC - 1));
                 __builtin_memcpy(&v[k], &t_, sizeof(TP));
             }
 #pragma unroll
@@ -945,9 +983,10 @@ __device__ __forceinline__ int wave_role(int wave) {       // 0 RA, 1 RB, 2 JA, 
 #ifndef ESKF_EP_F32_WAVES
 #define ESKF_EP_F32_WAVES 4
 #endif
-template <typename T, int NC>
-__global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8) ? ESKF_EP_F32_WAVES : 4) void eskf_epochs_kernel(EpochsArgs A, DevParams<T> prm) {
-    using L = ep::Lay<T, NC>;
+template <typename T, int NC, int PP>
+__global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8 && PP == 1) ? ESKF_EP_F32_WAVES : PP > 1 ? (Waves<NC>::N + 3) / 4 : 4)
+void eskf_epochs_kernel(EpochsArgs A, DevParams<T> prm) {
+    using L = ep::Lay<T, NC, PP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lds = reinterpret_cast<T*>(smem_raw);
     int* flags = reinterpret_cast<int*>(lds + L::O_FLAGS);
@@ -961,7 +1000,7 @@ __global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8) ? ES
     A.stamps = globalise(A.stamps);
     const int64_t b0 = (int64_t)blockIdx.x * L::NI;
     const int ni = (int)(A.a.B - b0 < L::NI ? A.a.B - b0 : L::NI);      // the block's instances (a ragged last block has fewer)
-    const int nca = (ni + 1) / 2;                                        // covariance wavefronts at work
+    const int nca = (ni + 2 * PP - 1) / (2 * PP);                        // covariance wavefronts at work
     unsigned long long wait_cycles[4] = {0, 0, 0, 0};
 #ifdef ESKF_X_EPSTAMPS
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -969,11 +1008,11 @@ __global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8) ? ES
     // (the recurrences and the Jacobian blocks are what the covariance wavefronts wait for: they go first on their SIMDs)
     const int role = wave_role<NC>(wave);
     if (role >= 0 && role < 4) __builtin_amdgcn_s_setprio(2);
-    if (role == 0) ep::role_ra<T, NC>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
-    else if (role == 1) ep::role_rb<T, NC>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
-    else if (role == 2) ep::role_j<T, NC, 0>(A, prm, lds, lane, nca, wait_cycles);
-    else if (role == 3) ep::role_j<T, NC, 1>(A, prm, lds, lane, nca, wait_cycles);
-    else if (role >= 4 && role - 4 < nca) ep::role_c<T, NC>(A, prm, lds, role - 4, lane, b0, ni, wait_cycles);
+    if (role == 0) ep::role_ra<T, L>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
+    else if (role == 1) ep::role_rb<T, L>(A, prm, lds, lane, b0, ni, nca, wait_cycles);
+    else if (role == 2) ep::role_j<T, L, 0>(A, prm, lds, lane, nca, wait_cycles);
+    else if (role == 3) ep::role_j<T, L, 1>(A, prm, lds, lane, nca, wait_cycles);
+    else if (role >= 4 && role - 4 < nca) ep::role_c<T, L>(A, prm, lds, role - 4, lane, b0, ni, wait_cycles);
 #ifdef ESKF_X_EPSTAMPS
     if (A.stamps && (threadIdx.x & 63) == 0) {
         unsigned long long* s = A.stamps + ((size_t)blockIdx.x * 16 + (role < 0 ? 15 : role)) * 8;
@@ -986,9 +1025,10 @@ __global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8) ? ES
 
 // ---- host side -----------------------------------------------------------------------------------------------------
 // DVI_ESKF_EPOCHS=0: runs with epochs of several predicts are enqueued epoch by epoch (the A/B, and the bitwise test of
-// this kernel against that path); DVI_ESKF_EPOCHS_NC=2|4|8|12 pins the block size
+// this kernel against that path); DVI_ESKF_EPOCHS_NC=2|4|8|10|12 pins the covariance wavefronts per block
 static const int g_epochs = []() { const char* e = getenv("DVI_ESKF_EPOCHS"); return e ? atoi(e) : -1; }();
 static const int g_epochs_nc = []() { const char* e = getenv("DVI_ESKF_EPOCHS_NC"); return e ? atoi(e) : 0; }();
+static const int g_epochs_pp = []() { const char* e = getenv("DVI_ESKF_EPOCHS_PP"); return e ? atoi(e) : 0; }();     // 1 | 2 (fp32) pins the pairs per wavefront
 
 static int n_compute_units() {
     static const int n_cu = []() {
@@ -1005,11 +1045,23 @@ static int n_compute_units() {
 // batches enqueued epoch by epoch.  Beyond one generation of twelve-wavefront blocks (B > 24 CUs) the epoch-by-epoch path is
 // the faster one (its lane-per-instance kernels work with all 64 lanes of a wavefront, the producers here with 2 NC of them)
 // and the launcher leaves the run to it unless DVI_ESKF_EPOCHS=1 asks for this kernel; 0 = the kernel serves nothing.
-static int epochs_nc(int64_t B) {
-    if (g_epochs_nc == 2 || g_epochs_nc == 4 || g_epochs_nc == 8 || g_epochs_nc == 10 || g_epochs_nc == 12) return g_epochs_nc;
+// fp32, two pairs per covariance wavefront (PP = 2; 32 / 40 / 48 instances per block): the producers' lanes are used twice
+// as well, the covariance wavefronts' own work is the same instructions.  One generation of 32-instance blocks takes
+// 101.6 us per frame whatever its fill (B = 8 192: 2.69e9 IMU steps/s against 2.57e9 epoch by epoch), 40 / 48 per block
+// 132 / 133 us (B = 10 240 / 12 288: level with the epoch-by-epoch path or behind it): the launcher takes PP = 2 where a
+// generation of 32-instance blocks is at least nine tenths full, B in [29 CUs, 32 CUs].  (DVI_ESKF_EPOCHS_PP=1 | 2 pins it.)
+// Returns the instances per block, 2 NC PP (PP = 2 with NC = 8 | 10 | 12, fp32 only: 32 | 40 | 48 instances).
+static int epochs_block(int64_t B, bool f32) {
+    const bool nc_pinned = g_epochs_nc == 2 || g_epochs_nc == 4 || g_epochs_nc == 8 || g_epochs_nc == 10 || g_epochs_nc == 12;
+    const bool pp2_ok = f32 && g_epochs_pp != 1;
+    if (nc_pinned) return 2 * g_epochs_nc * ((pp2_ok && g_epochs_pp == 2 && g_epochs_nc >= 8) ? 2 : 1);
     const int64_t cus = n_compute_units();
-    for (int nc : {2, 4, 8, 10, 12}) if ((B + 2 * nc - 1) / (2 * nc) <= cus) return nc;
-    return g_epochs == 1 ? 12 : 0;
+    if (g_epochs_pp != 2)
+        for (int nc : {2, 4, 8, 10, 12}) if ((B + 2 * nc - 1) / (2 * nc) <= cus) return 2 * nc;
+    if (pp2_ok && g_epochs_pp == 2)
+        for (int nc : {8, 10, 12}) if ((B + 4 * nc - 1) / (4 * nc) <= cus) return 4 * nc;
+    if (pp2_ok && B >= 29 * cus && B <= 32 * cus) return 32;
+    return g_epochs == 1 ? (pp2_ok && g_epochs_pp == 2 ? 48 : 24) : 0;
 }
 template <typename T>
 static int epochs_kernel_block_typed(int lpi, const StepArgs& a, const DevParams<T>& prm) {
@@ -1021,22 +1073,22 @@ static int epochs_kernel_block_typed(int lpi, const StepArgs& a, const DevParams
     }();
     const bool ok = lds_ok && g_epochs != 0 && lpi == 1 && !a.noise && !a.K_out && !a.sub_count && !prm.jfull && !prm.q_gyro &&
                     (prm.quirks & QK_Q1) && a.B > 0 && a.B < 0x7fffffffLL;
-    return ok ? 2 * epochs_nc(a.B) : 0;
+    return ok ? epochs_block(a.B, sizeof(T) == 4) : 0;
 }
 int epochs_kernel_block(int dtype, int lpi, const StepArgs& a, const HostParams& hp) {
     if (dtype == 0) return epochs_kernel_block_typed<double>(lpi, a, make_dev_params<double>(hp));
     return epochs_kernel_block_typed<float>(lpi, a, make_dev_params<float>(hp));
 }
-template <typename T, int NC>
+template <typename T, int NC, int PP = 1>
 static hipError_t launch_epochs_nc(const EpochsArgs& ea, const DevParams<T>& prm, hipStream_t stream) {
-    using L = ep::Lay<T, NC>;
+    using L = ep::Lay<T, NC, PP>;
     static_assert(L::BYTES <= 160 * 1024, "the block's LDS");
     // (more than 64 KB of dynamic LDS; runtimes that do not need to be told ignore it)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&eskf_epochs_kernel<T, NC>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&eskf_epochs_kernel<T, NC, PP>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)L::BYTES);
     (void)attr;
     const unsigned blocks = (unsigned)((ea.a.B + L::NI - 1) / L::NI);
-    hipLaunchKernelGGL((eskf_epochs_kernel<T, NC>), dim3(blocks), dim3(Waves<NC>::N * 64), L::BYTES, stream, ea, prm);
+    hipLaunchKernelGGL((eskf_epochs_kernel<T, NC, PP>), dim3(blocks), dim3(Waves<NC>::N * 64), L::BYTES, stream, ea, prm);
     return hipGetLastError();
 }
 template <typename T>
@@ -1055,8 +1107,17 @@ static hipError_t launch_epochs_typed(int lpi, const EpochsArgs& ea, const DevPa
         case 16: return launch_epochs_nc<T, 8>(ea, prm, stream);
         case 20: return launch_epochs_nc<T, 10>(ea, prm, stream);
         case 24: return launch_epochs_nc<T, 12>(ea, prm, stream);
-        default: return hipErrorInvalidValue;
+        default: break;
     }
+    if constexpr (sizeof(T) == 4) {
+        switch (ni) {
+            case 32: return launch_epochs_nc<T, 8, 2>(ea, prm, stream);
+            case 40: return launch_epochs_nc<T, 10, 2>(ea, prm, stream);
+            case 48: return launch_epochs_nc<T, 12, 2>(ea, prm, stream);
+            default: break;
+        }
+    }
+    return hipErrorInvalidValue;
 }
 // The 30-column FilterTraj rows (FilterTraj.py:12-41) of a run from its state snapshots: row r of instance b from
 // xlog[r][26][n_log], the run's last row from the (flushed) state record xs[36][B]

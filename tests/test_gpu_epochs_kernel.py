@@ -16,13 +16,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _child(batch, dtype, sched, nc="", frozen="000000", hold="1", timeout=600):
+def _child(batch, dtype, sched, nc="", frozen="000000", hold="1", timeout=600, pp=""):
     env = dict(os.environ)
     for k in ("DVI_ESKF_PRE_LEGACY", "DVI_ESKF_FUSED", "DVI_ESKF_FUSED_ROUNDS", "DVI_ESKF_RUN", "DVI_ESKF_RUN_ROUNDS", "DVI_ESKF_EPOCHS",
-              "DVI_ESKF_EPOCHS_NC", "DVI_ESKF_EPOCH_STREAMS"):
+              "DVI_ESKF_EPOCHS_NC", "DVI_ESKF_EPOCHS_PP", "DVI_ESKF_EPOCH_STREAMS"):
         env.pop(k, None)
     if nc:
         env["DVI_ESKF_EPOCHS_NC"] = nc
+    if pp:
+        env["DVI_ESKF_EPOCHS_PP"] = pp
     env["DVI_ESKF_EPOCHS"] = "1"        # (also where the launcher would leave a batch of this size to the epoch-by-epoch path)
     env["DVI_ESKF_VERBOSE"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_epochs_child.py"), str(batch), dtype, ROOT, sched, frozen, hold], cwd=ROOT,
@@ -36,6 +38,15 @@ def _child(batch, dtype, sched, nc="", frozen="000000", hold="1", timeout=600):
 def test_run_of_epochs_in_one_launch_equals_the_epochs_one_by_one(batch, dtype, nc):
     """the ragged 33 / 33 / 34 schedule of BASELINE config #5 (three camera frames), every block size"""
     _child(batch, dtype, "33,33,34", nc)
+
+
+@pytest.mark.parametrize("batch,nc", [(5, "8"), (1000, "8"), (700, "10"), (1500, "12"), (8192, "")])
+def test_two_pairs_of_instances_per_covariance_wavefront(batch, nc):
+    """fp32: a covariance wavefront keeps the rows of four instances (32 / 40 / 48 instances per block), ragged blocks included"""
+    _child(batch, "f32", "33,33,34", nc, pp="2")
+    if batch == 1000:
+        _child(batch, "f32", "2,7,0,3,12,5", nc, pp="2")
+        _child(515, "f32", "4,3,5", nc, frozen="101001", hold="0", pp="2")
 
 
 @pytest.mark.parametrize("batch,dtype,sched", [(777, "f64", "10,10,10,10,10,10"), (130, "f32", "2,7,3,12,5"), (64, "f64", "2,2,2,2,2,2,2,2,2")])

@@ -9,7 +9,8 @@ asm = "/tmp/ep.s"
 if not os.environ.get("EP_NO_BUILD"):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-disable-machine-licm", "-S",
                            "--cuda-device-only", "-o", asm, os.path.join(root, "dvi_ekf_amd/csrc/eskf_epochs.hip")] + sys.argv[3:], stderr=subprocess.DEVNULL)
-name = "_ZN4eskf18eskf_epochs_kernelI%sLi%sEEEvNS_10EpochsArgsENS_9DevParamsIT_EE" % (dt, nc)
+pp = os.environ.get("EP_PP", "1")
+name = "_ZN4eskf18eskf_epochs_kernelI%sLi%sELi%sEEEvNS_10EpochsArgsENS_9DevParamsIT_EE" % (dt, nc, pp)
 lines, on = [], False
 for l in open(asm):
     if l.startswith(name + ":"):

@@ -64,4 +64,11 @@ for w, (nm, slots) in names.items():
     if ticks_per_us:
         row["busy_us_per_frame"] = (tot - waits) / ticks_per_us / E
     out[nm] = row
-print(json.dumps(out, indent=1))
+if os.environ.get("STAMPS_BRIEF"):
+    print("B %d %s: %.1f us/frame, %.3e IMU steps/s, %d blocks" % (B, str(dtype)[-7:], out["us_per_frame"], out["imu_steps_per_s"], nblk))
+    for nm in ("RA", "RB", "JA", "JB", "C0"):
+        r = out[nm]
+        print("  %s busy %.2f (%.1f us/frame) | " % (nm, r["busy frac"], r.get("busy_us_per_frame", float("nan"))) +
+              ", ".join("%s %.2f" % (k[5:-5], v) for k, v in r.items() if k.startswith("wait ")))
+else:
+    print(json.dumps(out, indent=1))
