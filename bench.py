@@ -104,15 +104,40 @@ def _cpu_baseline_run(c_oracle, prm, wl, seconds_target, cores):
 BYTES_PREDICT = {"f64": 5432, "f32": 2716}
 FLOP_PER_PREDICT = 7213
 FLOP_PER_UPDATE = 12492
-VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 78.6}       # MI355X_MICROARCH.md: vector fp64 78.6 TF; fp32 at the same rate unless packed (157.3)
+VALU_PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}      # MI355X_MICROARCH.md: vector fp64 78.6 TF, fp32 157.3 TF -- the rate of a plain v_fmac_f32
+                                                    # (measured, tools/pk_micro.hip -> profiles/r05_packed_fp32_micro.txt: 128 multiply-adds per clock and CU,
+                                                    # with or without the DPP operand; v_pk_fma_f32 doubles it only with both operands in the lane)
 
 
-def _flop_roofline(predicts_per_s, updates_per_s, dtype):
+def _valu_counters():
+    """profiles/valu_counters.json: vector-ALU issue share per regime from the committed rocprofv3 SQ-counter passes
+    (tools/prof_round.sh, tools/summarize_sq.py) -- constants of the committed profile, NOT measured in this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "valu_counters.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def _valu_issue(key):
+    c = _valu_counters()
+    e = c.get(key)
+    if not e:
+        return None
+    return {"valu_busy": e["valu_busy"], "formula": c.get("formula"), "source": "static: profiles/valu_counters.json <- " + str(c.get("source")),
+            "kernels": [{k: kk[k] for k in ("kernel", "launches", "valu_busy", "SQ_INSTS_VALU_per_wave")} for kk in e.get("kernels", [])]}
+
+
+def _flop_roofline(predicts_per_s, updates_per_s, dtype, counters_key=None):
     tf = (predicts_per_s * FLOP_PER_PREDICT + updates_per_s * FLOP_PER_UPDATE) / 1e12
     return {"bound": "valu", "achieved": tf, "peak": VALU_PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS[dtype],
             "flop_per_predict": FLOP_PER_PREDICT, "flop_per_update": FLOP_PER_UPDATE,
-            "note": "covariance arithmetic only, as performed (Fx block structure exploited); resident regime: P stays on chip across "
-                    "the predicts, so no HBM fraction is claimed (SURVEY 8(d)); fp32 peak quoted unpacked (packed: 157.3)"}
+            "valu_issue": _valu_issue(counters_key) if counters_key else None,
+            "note": "frac: covariance arithmetic only, as performed (Fx block structure exploited), against the vector peak of the dtype; "
+                    "resident regime: P stays on chip across the predicts, so no HBM fraction is claimed (SURVEY 8(d)).  valu_issue: the "
+                    "share of the chip's vector-ALU issue time the regime's kernels used, by the SQ counters of the committed profile -- "
+                    "the rest of the distance to `frac` is instructions that are not multiply-adds of the covariance (lane exchanges, "
+                    "addressing, the lane-per-instance chains) and idle lanes (24 of 32 per instance)"}
 
 
 def secondary_block(dev, measure_pairs):
@@ -181,7 +206,7 @@ def secondary_block(dev, measure_pairs):
     out["epochs_10to1_fp64"] = {
         "batch": B10, "predicts_per_epoch": N10, "ms_per_epoch": best * 1e3, "value": B10 / best, "unit": "epochs/s",
         "predict_steps_per_s": B10 * N10 / best, "launch_pattern": "one dvi_eskf_epoch call per epoch",
-        "roofline": _flop_roofline(B10 * N10 / best, B10 / best, "f64"),
+        "roofline": _flop_roofline(B10 * N10 / best, B10 / best, "f64", "epochs_10to1_fp64"),
         "hbm_epoch_formula": {"bytes_per_epoch": byt, "formula": "2*300w + 2*36w + 7N*w + 8w, w = 8, N = 10", "achieved": B10 * byt / best / 1e9,
                               "unit": "GB/s", "frac": B10 * byt / best / 1e9 / HBM_PEAK_GBS},
         "finite": bool(torch.isfinite(f.x).all())}
@@ -216,7 +241,7 @@ def secondary_block(dev, measure_pairs):
                 "value": B5 * wl5.n_steps / t5, "unit": "IMU steps/s (instance-steps)",
                 "launch_pattern": "one dvi_eskf_run_epochs call for the whole run",
                 "regime": "camera noise 0.2 / 1 deg, frozen extrinsics (with the default YAML noise the reference filter stays bounded for ~800 steps only)",
-                "roofline": _flop_roofline(B5 * wl5.n_steps / t5, B5 * E5 / t5, name),
+                "roofline": _flop_roofline(B5 * wl5.n_steps / t5, B5 * E5 / t5, name, "config5_%s_B%d" % (name, B5)),
                 "skipped_updates": int((st & 1).sum()), "finite": bool(torch.isfinite(f.x).all())}
             del f, snap
         del om, acc
@@ -228,7 +253,7 @@ def secondary_block(dev, measure_pairs):
     ach = BYTES_PER_PAIR_F64 * 8192 / (m8["kern_ms"] * 1e-3) / 1e9
     out["pairs_fp64_B8192"] = {"batch": 8192, "value": 8192 / (m8["kern_ms"] * 1e-3), "unit": "pair-steps/s", "kernel_ms": m8["kern_ms"],
                                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                            "bytes_per_pair": BYTES_PER_PAIR_F64,
+                                            "bytes_per_pair": BYTES_PER_PAIR_F64, "valu_issue": _valu_issue("pairs_fp64_B8192"),
                                             "note": "in a run no covariance leaves the chip between the first and the last step at this batch: "
                                                     "the algorithmic-bytes fraction is a throughput scale, not a traffic claim"},
                                "valid": m8["ok"]}
@@ -585,7 +610,7 @@ def main():
         kern_ms_eager = float(np.mean([a.elapsed_time(b) for a, b in ev])) / per_ev
 
         # the same measurement at a batch whose working set does not fit the 256 MiB Infinity Cache (the headline
-        # batch's ~225 MB does): what the step sustains when it has to stream from HBM
+        # batch's ~225 MB does, EXPERIMENTS.md "Round 4"): what the step sustains when it has to stream from HBM
         streaming = None
         if rank == 0 and world == 1 and dist is None and args.mode == "pair" and not args.no_streaming and not args.no_graph:
             Bs = args.streaming_batch
@@ -634,6 +659,7 @@ def main():
         achieved = BYTES_PER_PAIR_F64 * B / (kern_ms * 1e-3) / 1e9
         achieved_wall = BYTES_PER_PAIR_F64 * B / (elapsed / K) / 1e9
         traffic, traffic_source = None, None
+        measured_cfg = False
         tf = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.exists(tf):
             try:
@@ -732,9 +758,10 @@ def main():
                 # what actually crossed the fabric, against the same peak: `frac` prices the ALGORITHMIC bytes (a quarter of the
                 # covariances never leaves LDS between two steps of a run, so the fabric moves fewer)
                 "frac_traffic": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "valu_issue": _valu_issue("headline_pairs_fp64_B65536") if measured_cfg else None,
                 "bound_note": "priced against HBM as SURVEY 8(d) defines the metric; by the counters of the committed profile neither pipe "
                               "is saturated at this batch -- the fabric moves `traffic` at `frac_traffic` of peak, the vector ALUs are "
-                              "about 60 % issue-busy (profiles/*_sq_counters.txt): what the step lacks is overlap of the two",
+                              "issue-busy for `valu_issue.valu_busy` of the kernel's time: what the step lacks is overlap of the two",
                 "kernel": ("eskf_run_kernel: ONE launch per horizon (%d steps; the time loop, every step's pre phase and its "
                            "row-resident covariance rounds inside; between two steps of a launch the covariances of a quarter of "
                            "the instances stay in LDS); achieved = algorithmic bytes of a step / (launch duration / steps "

@@ -4223,7 +4223,7 @@ static const bool g_pre_legacy = []() { const char* e = getenv("DVI_ESKF_PRE_LEG
 // in a run against 7.7 / 7.1 for 32 / 64), at 32 768 they are 2.7 (7.5 against 8.2 for 64).
 // (The first complete build of the kernel lost to the two kernels between 32 768 and 65 536 -- a launch there is two
 // generations of blocks that are all in their pre phase at the same time -- and won below and above; what turned the middle
-// around were the code-generation fixes of DESIGN.md section 6, "Round 4": no FLAT accesses, no spilled scalar registers.)
+// around were the code-generation fixes of EXPERIMENTS.md, "Round 4": no FLAT accesses, no spilled scalar registers.)
 static int pick_rounds(int64_t B, const float (&T1)[4], const float (&T2)[4]) {
     static const int n_cu = []() {
         int dev = 0, n = 0;

@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box): tools/prof_round.sh <tag> [parts, default 1234]  -- the round's committed profile set:
 #  1. kernel trace + FETCH / WRITE PMC passes of the bench workload (tools/prof_full.sh) and the traffic constant bench.py reports
-#  2. the bench lines (the driver's short call and the default; both carry the `secondary` block)
-#  3. SQ counters (vector-ALU issue share) of the bench workload and of the resident regimes: 10:1 epochs at B = 65 536, config #5's
+#  2. (after 3, whose constants they quote) the bench lines: the driver's short call and the default; both carry the `secondary` block
+#  3. SQ counters (vector-ALU issue share; condensed into profiles/valu_counters.json, which bench.py quotes) of the bench workload and of the resident regimes: 10:1 epochs at B = 65 536, config #5's
 #     schedule at B = 1 024 / 8 192 in both precisions, pair steps at B = 8 192 -- with the kernel stats of the same commands
 #  4. where a frame of the long-horizon kernel goes (tools/exp_epoch_stamps.py on the -DESKF_X_EPSTAMPS build, when
 #     variants_tmp/lib_epstamps.so is there)
@@ -20,10 +20,6 @@ json.dump({"hbm_bytes_per_step": d["hbm_bytes_per_launch"], "read_bytes_x2_corre
           open("profiles/traffic_per_launch.json", "w"), indent=1)
 PY
 fi
-if has 2; then
-python bench.py --steps 20 --warmup 5 > profiles/${tag}_final_bench_short.json 2> gpurun_out/${tag}_bench_short.err || exit 1
-python bench.py > profiles/${tag}_final_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
-fi
 if has 3; then
 bash tools/pmc.sh ${tag}_sq "$SQ" | grep -E "run_kernel|step_kernel|pre4|cov_rows" > profiles/${tag}_sq_counters.txt
 {
@@ -38,6 +34,11 @@ bash tools/pmc.sh ${tag}_sq "$SQ" | grep -E "run_kernel|step_kernel|pre4|cov_row
   bash tools/prof_cmd.sh ${tag}_ks_small $PWD/tools/bench_configs.py small
   bash tools/prof_cmd.sh ${tag}_ks_c5 $PWD/tools/sweep_config5.py 1024,8192 2000
 } > profiles/${tag}_kernel_stats_resident.txt 2>&1
+python tools/summarize_sq.py ${tag} > gpurun_out/${tag}_summarize_sq.txt
+fi
+if has 2; then
+python bench.py --steps 20 --warmup 5 > profiles/${tag}_final_bench_short.json 2> gpurun_out/${tag}_bench_short.err || exit 1
+python bench.py > profiles/${tag}_final_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
 fi
 if has 4 && [ -f variants_tmp/lib_epstamps.so ]; then
   {
@@ -47,7 +48,7 @@ if has 4 && [ -f variants_tmp/lib_epstamps.so ]; then
     DVI_ESKF_EPOCHS=1 DVI_ESKF_EPOCHS_NC=8 DVI_ESKF_LIB=$PWD/variants_tmp/lib_epstamps.so python tools/exp_epoch_stamps.py 8192 f32 2000 2>&1 | grep -v "^dvi_ekf_amd:"
   } > profiles/${tag}_epochs_kernel_stamps.txt
 fi
-mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* profiles/traffic_per_launch.json gpurun_out/profiles_${tag}/
+mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* profiles/traffic_per_launch.json profiles/valu_counters.json gpurun_out/profiles_${tag}/
 has 2 && python -c "
 import json
 for f in ('profiles/${tag}_final_bench_short.json', 'profiles/${tag}_final_bench.json'):
