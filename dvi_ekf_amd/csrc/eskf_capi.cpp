@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <vector>
+#include <cstdio>
 #include <cstring>
 #include <new>
 
@@ -775,6 +776,12 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
                        sc->n_epochs >= 2 &&
                        eskf::epoch_sub_batches_ok(h->lpi, part, part, shortest, h->d_noise != nullptr, false, h->d_aux != nullptr);
     if (split) {
+        static const bool verbose = []() { const char* e = getenv("DVI_ESKF_VERBOSE"); return e && e[0] == '1'; }();
+        static bool said = false;
+        if (verbose && !said) {
+            said = true;
+            fprintf(stderr, "dvi_eskf: runs of epochs go epoch by epoch, %d parts of the batch on %d streams\n", n_parts, n_parts);
+        }
         DeviceGuard g(h->device);
         hipStream_t cs = (hipStream_t)stream;
         if (!g.ok || !ensure_side_streams(h)) return DVI_ESKF_EHIP;

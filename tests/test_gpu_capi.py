@@ -291,6 +291,26 @@ def test_run_epochs_error_after_the_fork_still_joins_the_side_streams(tmp_path):
     assert "split child ok" in p.stdout
 
 
+@pytest.mark.parametrize("parts,B,dtype", [("3", 8448, "f64"), ("4", 8448, "f32"), ("8", 9216, "f64")])
+def test_run_epochs_on_k_streams_equals_epoch_by_epoch(parts, B, dtype):
+    """DVI_ESKF_EPOCH_STREAMS=k: k parts of an under-filled batch (multiples of 64 instances) run their epochs on k streams of
+    the handle's own.  Same bits as the epochs called one by one (child process: the switch is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("DVI_ESKF_EPOCHS", "DVI_ESKF_EPOCHS_NC", "DVI_ESKF_EPOCHS_PP", "DVI_ESKF_EPOCH_STREAMS_MIN", "DVI_ESKF_EPOCH_STREAMS_MAX"):
+        env.pop(k, None)
+    env["DVI_ESKF_EPOCH_STREAMS"] = parts
+    env["DVI_ESKF_EPOCHS"] = "0"        # (the epoch-by-epoch path also where the long-horizon kernel would take the run)
+    env["DVI_ESKF_VERBOSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "_streams_child.py"), root, str(B), dtype], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert "streams child ok" in p.stdout
+    assert "%s parts of the batch" % parts in p.stderr, p.stderr[-2000:]
+
+
 @pytest.mark.parametrize("dtype,per_instance,B", [("float64", False, 2176), ("float64", True, 8320), ("float32", False, 8320), ("float64", False, 8320)])
 def test_run_epochs_on_two_streams_equals_epoch_by_epoch(dtype, per_instance, B):
     """An under-filled batch (B a multiple of 128, 2 048 <= B <= 16 384, every epoch with >= 2 predicts, no log rows):
