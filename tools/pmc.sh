@@ -5,7 +5,7 @@ tag=$1; ctr=$2; shift; shift
 R=$PWD
 mkdir -p gpurun_out/$tag
 for s in "$@"; do export "$s"; done
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/$tag/pmc -- python3 $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-streaming --sustain-seconds 0.05 > /dev/null 2> $R/gpurun_out/$tag/pmc.err) || exit 1
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --pmc $ctr --output-format csv -d $R/gpurun_out/$tag/pmc -- python3 $R/bench.py --steps 64 --warmup 8 --no-cpu-baseline --no-streaming --no-secondary --sustain-seconds 0.05 > /dev/null 2> $R/gpurun_out/$tag/pmc.err) || exit 1
 python - <<PY | tee gpurun_out/$tag/pmc.txt
 import collections, csv, glob
 fn = glob.glob("gpurun_out/$tag/pmc/**/*_counter_collection.csv", recursive=True)[0]

@@ -5,7 +5,7 @@ tag=$1
 R=$PWD
 mkdir -p gpurun_out/$tag
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 128 --warmup 16 --no-cpu-baseline --no-streaming --sustain-seconds 0.05"
+ARGS="--steps 128 --warmup 16 --no-cpu-baseline --no-streaming --no-secondary --sustain-seconds 0.05"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$tag/trace -- python3 $R/bench.py $ARGS > $R/gpurun_out/$tag/bench_trace.json 2> $R/gpurun_out/$tag/trace.err || exit 1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$tag/pmc_fetch -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/$tag/fetch.err || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$tag/pmc_write -- python3 $R/bench.py $ARGS > /dev/null 2> $R/gpurun_out/$tag/write.err || exit 1

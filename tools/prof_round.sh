@@ -43,9 +43,9 @@ fi
 if has 4 && [ -f variants_tmp/lib_epstamps.so ]; then
   {
     for cfg in "1024 f32" "1024 f64" "6144 f32" "6144 f64"; do
-      DVI_ESKF_LIB=$PWD/variants_tmp/lib_epstamps.so python tools/exp_epoch_stamps.py $cfg 2000 2>&1 | grep -v "^dvi_ekf_amd:"
+      STAMPS_BRIEF=1 DVI_ESKF_LIB=$PWD/variants_tmp/lib_epstamps.so python tools/exp_epoch_stamps.py $cfg 2000 2>&1 | grep -v "^dvi_ekf_amd:\|amdgpu.ids"
     done
-    DVI_ESKF_EPOCHS=1 DVI_ESKF_EPOCHS_NC=8 DVI_ESKF_LIB=$PWD/variants_tmp/lib_epstamps.so python tools/exp_epoch_stamps.py 8192 f32 2000 2>&1 | grep -v "^dvi_ekf_amd:"
+    STAMPS_BRIEF=1 DVI_ESKF_LIB=$PWD/variants_tmp/lib_epstamps.so python tools/exp_epoch_stamps.py 8192 f32 2000 2>&1 | grep -v "^dvi_ekf_amd:\|amdgpu.ids"
   } > profiles/${tag}_epochs_kernel_stamps.txt
 fi
 mkdir -p gpurun_out/profiles_${tag} && cp profiles/${tag}_* profiles/traffic_per_launch.json profiles/valu_counters.json gpurun_out/profiles_${tag}/
