@@ -493,7 +493,12 @@ def test_fp32_variant_tracks_oracle_loosely():
 # step from the fp64 oracle's state, relative to the instance's magnitude.  fp32 keeps 7 digits and the
 # update subtracts K S K^T from a P that shrinks by up to ten orders of magnitude in its measured block
 # (R_theta ~ 3e-14 against a prior of 1e-5), so the covariance tolerance is set by the LARGEST entry of P.
-FP32_UPDATE_TOL_X, FP32_UPDATE_TOL_P = 5e-4, 5e-3
+# Tolerances = what the kernels measure on MI355X (deterministic: no atomics, fixed operation order) x 3, per regime -- round 5;
+# until then one pair (5e-4, 5e-3) covered all of them and would not have noticed a tenfold regression of the frozen runs.
+#   (golden, frozen): (predict x, predict P, update x, update P, fused epoch x, fused epoch P)
+FP32_MEASURED = {(False, 0): (1.3e-7, 1.1e-7, 1.9e-4, 1.7e-5, 3.7e-4, 3.4e-5),
+                 (False, 1): (1.3e-7, 9.4e-8, 4.0e-7, 7.1e-7, 9.0e-7, 1.4e-6),
+                 (True, 0): (1.3e-7, 7.2e-7, 3.7e-6, 3.0e-6, 1.2e-5, 8.0e-6)}
 
 
 @pytest.mark.parametrize("golden,frozen,lpi", [(False, (0,) * 6, None), (False, (1,) * 6, None), (True, (0,) * 6, None),
@@ -541,9 +546,9 @@ def test_fp32_forced_single_step_update_parity(golden, frozen, lpi):
         eP_s = max(eP_s, relP(s["P"].double().cpu().numpy(), o.P))
     print(f"fp32 forced single step (golden={golden}, frozen={frozen[0]}, lanes={lpi}): predict x {ex_p:.1e} P {eP_p:.1e} | "
           f"update x {ex_u:.1e} P {eP_u:.1e} | fused epoch x {ex_s:.1e} P {eP_s:.1e}")
-    assert ex_p <= 2e-5 and eP_p <= 2e-4
-    assert ex_u <= FP32_UPDATE_TOL_X and eP_u <= FP32_UPDATE_TOL_P
-    assert ex_s <= FP32_UPDATE_TOL_X and eP_s <= FP32_UPDATE_TOL_P
+    m = FP32_MEASURED[(golden, frozen[0])]
+    for got, meas, what in zip((ex_p, eP_p, ex_u, eP_u, ex_s, eP_s), m, ("predict x", "predict P", "update x", "update P", "epoch x", "epoch P")):
+        assert got <= 3.0 * meas, (what, got, meas)
 
 
 @pytest.mark.parametrize("lpi", [None, 2, 32])
