@@ -2740,8 +2740,10 @@ __device__ __forceinline__ void spread_rows(float v, float& X, float& Y) {
 }
 template <int LANE, bool FIRST = false>
 __device__ __forceinline__ void dpp_fmac(float& acc, float src, float mul) {
-    if constexpr (FIRST) acc = 0.0f;
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+    // (the accumulator's first term is the product itself: one instruction instead of a zero and a multiply-add.  fp32 only --
+    //  v_mul_f64 has no DPP form; differs from fma(a, b, +0) in the sign of a zero product, nowhere else)
+    if constexpr (FIRST) asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(acc) : "v"(src), "v"(mul), "n"(LANE));
+    else asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(LANE));
 }
 template <int LANE>
 __device__ __forceinline__ float dpp_bcast(float src) {
@@ -2781,8 +2783,8 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
             T b = v[3 + r];
             J.template mac<J_A + 3 * r>(b, v[6]); J.template mac<J_A + 3 * r + 1>(b, v[7]); J.template mac<J_A + 3 * r + 2>(b, v[8]);
             o[3 + r] = b;
-            T c = T(0);
-            J.template mac<J_TH + 3 * r>(c, v[6]); J.template mac<J_TH + 3 * r + 1>(c, v[7]); J.template mac<J_TH + 3 * r + 2>(c, v[8]);
+            T c;
+            J.template mac<J_TH + 3 * r, true>(c, v[6]); J.template mac<J_TH + 3 * r + 1>(c, v[7]); J.template mac<J_TH + 3 * r + 2>(c, v[8]);
             o[6 + r] = c;
         });
         T o15 = v[15], o16 = v[16];
@@ -2817,8 +2819,8 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
         T o[3];
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            T w = T(0);
-            J.template mac<J_DM + 4 * r + 3>(w, v[15]);
+            T w;
+            J.template mac<J_DM + 4 * r + 3, true>(w, v[15]);
             J.template mac<J_DM + 4 * r>(w, v[9]); J.template mac<J_DM + 4 * r + 1>(w, v[10]); J.template mac<J_DM + 4 * r + 2>(w, v[11]);
             constexpr int e0 = Q1 ? 19 : 21;
             J.template mac<J_EM + 3 * r>(w, v[e0]); J.template mac<J_EM + 3 * r + 1>(w, v[e0 + 1]); J.template mac<J_EM + 3 * r + 2>(w, v[e0 + 2]);
@@ -2841,14 +2843,14 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
         for (int k = 0; k < 9; ++k) c[k] = lds_load1(col + k * PS);
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
-            T x = T(0);                 // dt c[3+r], used twice (see fx_apply_store_dpp)
-            J.template mac<J_DT>(x, c[3 + r]);
+            T x;                        // dt c[3+r], used twice (see fx_apply_store_dpp)
+            J.template mac<J_DT, true>(x, c[3 + r]);
             o[r] = c[r] + x;
             T b = c[3 + r];
             J.template mac<J_A + 3 * r>(b, c[6]); J.template mac<J_A + 3 * r + 1>(b, c[7]); J.template mac<J_A + 3 * r + 2>(b, c[8]);
             o[3 + r] = b;
-            T t = T(0);
-            J.template mac<J_TH + 3 * r>(t, c[6]); J.template mac<J_TH + 3 * r + 1>(t, c[7]); J.template mac<J_TH + 3 * r + 2>(t, c[8]);
+            T t;
+            J.template mac<J_TH + 3 * r, true>(t, c[6]); J.template mac<J_TH + 3 * r + 1>(t, c[7]); J.template mac<J_TH + 3 * r + 2>(t, c[8]);
             o[6 + r] = t;
             J.template mac<J_BM + 3 * r>(x, c[6]); J.template mac<J_BM + 3 * r + 1>(x, c[7]); J.template mac<J_BM + 3 * r + 2>(x, c[8]);
             u[r] = x;
@@ -2873,8 +2875,8 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
         static_for<0, 3>([&](auto R) {
             constexpr int r = decltype(R)::value;
             static_for<0, 6>([&](auto K) { J.template mac<J_CM + 6 * r + decltype(K)::value>(u[r], c[decltype(K)::value]); });
-            T y = T(0);
-            J.template mac<J_DM + 4 * r + 3>(y, c[6]);
+            T y;
+            J.template mac<J_DM + 4 * r + 3, true>(y, c[6]);
             J.template mac<J_DM + 4 * r>(y, c[0]); J.template mac<J_DM + 4 * r + 1>(y, c[1]); J.template mac<J_DM + 4 * r + 2>(y, c[2]);
             w[r] = y;
         });
