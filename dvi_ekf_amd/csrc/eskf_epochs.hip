@@ -605,38 +605,6 @@ __device__ __forceinline__ void role_j(const EpochsArgs& A, const DevParams<T>& 
     }
 }
 
-// P' += Fi Q Fi^T on the row-resident P (Filter.py:263-264,349): diagonal entries 3..14 <- Q[i - 3], 17 <- Q[12], each
-// added in the two lanes that own the row -- the adds of rowk::noise_rows under the same constant lane sets, but with
-// EXEC written directly (two scalar moves of an inline constant per entry and one restore at the end instead of a mask
-// pair, a save and a restore per entry: 40 instructions instead of 65 -- at one covariance wavefront per SIMD every
-// instruction of whatever kind is a slot of the wavefront's own time).  All lanes are active on entry.
-__device__ __forceinline__ void noise_diag_exec(const DevParams<double>& prm, double (&p)[24]) {
-#define EP_NQ(K, ROW) "s_mov_b32 exec_lo, %[m" #ROW "]\n s_mov_b32 exec_hi, %[m" #ROW "]\n v_add_f64 %[p" #ROW "], %[p" #ROW "], %[q" #K "]\n"
-    asm volatile(EP_NQ(0, 3) EP_NQ(1, 4) EP_NQ(2, 5) EP_NQ(3, 6) EP_NQ(4, 7) EP_NQ(5, 8) EP_NQ(6, 9) EP_NQ(7, 10) EP_NQ(8, 11) EP_NQ(9, 12)
-                 EP_NQ(10, 13) EP_NQ(11, 14) EP_NQ(12, 17) "s_mov_b64 exec, -1\n"
-                 : [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]), [p8] "+v"(p[8]), [p9] "+v"(p[9]),
-                   [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p17] "+v"(p[17])
-                 : [q0] "s"(prm.qd[0]), [q1] "s"(prm.qd[1]), [q2] "s"(prm.qd[2]), [q3] "s"(prm.qd[3]), [q4] "s"(prm.qd[4]), [q5] "s"(prm.qd[5]),
-                   [q6] "s"(prm.qd[6]), [q7] "s"(prm.qd[7]), [q8] "s"(prm.qd[8]), [q9] "s"(prm.qd[9]), [q10] "s"(prm.qd[10]), [q11] "s"(prm.qd[11]),
-                   [q12] "s"(prm.qd[12]),
-                   [m3] "n"(1 << 3), [m4] "n"(1 << 4), [m5] "n"(1 << 5), [m6] "n"(1 << 6), [m7] "n"(1 << 7), [m8] "n"(1 << 8), [m9] "n"(1 << 9),
-                   [m10] "n"(1 << 10), [m11] "n"(1 << 11), [m12] "n"(1 << 12), [m13] "n"(1 << 13), [m14] "n"(1 << 14), [m17] "n"(1 << 17));
-#undef EP_NQ
-}
-__device__ __forceinline__ void noise_diag_exec(const DevParams<float>& prm, float (&p)[24]) {
-#define EP_NQ(K, ROW) "s_mov_b32 exec_lo, %[m" #ROW "]\n s_mov_b32 exec_hi, %[m" #ROW "]\n v_add_f32 %[p" #ROW "], %[p" #ROW "], %[q" #K "]\n"
-    asm volatile(EP_NQ(0, 3) EP_NQ(1, 4) EP_NQ(2, 5) EP_NQ(3, 6) EP_NQ(4, 7) EP_NQ(5, 8) EP_NQ(6, 9) EP_NQ(7, 10) EP_NQ(8, 11) EP_NQ(9, 12)
-                 EP_NQ(10, 13) EP_NQ(11, 14) EP_NQ(12, 17) "s_mov_b64 exec, -1\n"
-                 : [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]), [p8] "+v"(p[8]), [p9] "+v"(p[9]),
-                   [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p17] "+v"(p[17])
-                 : [q0] "s"(prm.qd[0]), [q1] "s"(prm.qd[1]), [q2] "s"(prm.qd[2]), [q3] "s"(prm.qd[3]), [q4] "s"(prm.qd[4]), [q5] "s"(prm.qd[5]),
-                   [q6] "s"(prm.qd[6]), [q7] "s"(prm.qd[7]), [q8] "s"(prm.qd[8]), [q9] "s"(prm.qd[9]), [q10] "s"(prm.qd[10]), [q11] "s"(prm.qd[11]),
-                   [q12] "s"(prm.qd[12]),
-                   [m3] "n"(1 << 3), [m4] "n"(1 << 4), [m5] "n"(1 << 5), [m6] "n"(1 << 6), [m7] "n"(1 << 7), [m8] "n"(1 << 8), [m9] "n"(1 << 9),
-                   [m10] "n"(1 << 10), [m11] "n"(1 << 11), [m12] "n"(1 << 12), [m13] "n"(1 << 13), [m14] "n"(1 << 14), [m17] "n"(1 << 17));
-#undef EP_NQ
-}
-
 // ---- C: the covariance of PP pairs of instances, rows in registers for the whole run -----------------------------
 // (the 32-lanes-per-instance / DPP / SLIM path of cov_rows_body, cut at its phase boundaries: load | predict | update +
 //  reset | store -- same statements in the same order.  PP = 2: the wavefront does every phase for its first pair, then
@@ -922,11 +890,7 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
             if (!last) {
                 const int st_ = row < 12 ? 25 * row : 26 * (23 - row) + 1;
                 T* rp_ = sBp + st_;
-                static_for<0, 24>([&](auto JJ) {
-                    constexpr int j = decltype(JJ)::value;
-                    constexpr unsigned long long m32 = (0x00ffffffull >> j) << j, m64 = m32 | (m32 << 32);
-                    if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, pr[j]);
-                });
+                store_row_masked((unsigned)(size_t)(__attribute__((address_space(3))) T*)rp_, pr);
                 wave_sync();
                 const unsigned rw_ = (unsigned)row;
                 const unsigned lb_ = (unsigned)(size_t)(__attribute__((address_space(3))) T*)sBp;
@@ -942,11 +906,7 @@ __device__ __forceinline__ void role_c(const EpochsArgs& A, const DevParams<T>& 
     for (int pp = 0; pp < PP; ++pp) {
         const int st_ = row < 12 ? 25 * row : 26 * (23 - row) + 1;
         T* rp_ = sB[pp] + st_;
-        static_for<0, 24>([&](auto JJ) {
-            constexpr int j = decltype(JJ)::value;
-            constexpr unsigned long long m32 = (0x00ffffffull >> j) << j, m64 = m32 | (m32 << 32);
-            if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[pp][j]);
-        });
+        store_row_masked((unsigned)(size_t)(__attribute__((address_space(3))) T*)rp_, p[pp]);
         wave_sync();
         if (valid[pp]) {
             char* gPb_ = reinterpret_cast<char*>(reinterpret_cast<T*>(a.P) + inst[pp] * 300);

@@ -2506,11 +2506,42 @@ __device__ __forceinline__ void add_in_row_lanes(float& p, float q) {
     unsigned long long saved;
     asm("s_and_saveexec_b64 %1, %3\n\tv_add_f32 %0, %0, %2\n\ts_mov_b64 exec, %1" : "+v"(p), "=&s"(saved) : "s"(q), "s"(mask) : "scc");
 }
+// P' += Fi Q Fi^T on the row-resident P (Filter.py:263-264,349): diagonal entries 3..14 <- Q[i - 3], 17 <- Q[12], each
+// added in the two lanes that own the row -- the adds of rowk::noise_rows under the same constant lane sets, but with
+// EXEC written directly (two scalar moves of an inline constant per entry and one restore at the end instead of a mask
+// pair, a save and a restore per entry: 40 instructions instead of 65 -- at one covariance wavefront per SIMD every
+// instruction of whatever kind is a slot of the wavefront's own time).  All lanes are active on entry.
+__device__ __forceinline__ void noise_diag_exec(const DevParams<double>& prm, double (&p)[24]) {
+#define EP_NQ(K, ROW) "s_mov_b32 exec_lo, %[m" #ROW "]\n s_mov_b32 exec_hi, %[m" #ROW "]\n v_add_f64 %[p" #ROW "], %[p" #ROW "], %[q" #K "]\n"
+    asm volatile(EP_NQ(0, 3) EP_NQ(1, 4) EP_NQ(2, 5) EP_NQ(3, 6) EP_NQ(4, 7) EP_NQ(5, 8) EP_NQ(6, 9) EP_NQ(7, 10) EP_NQ(8, 11) EP_NQ(9, 12)
+                 EP_NQ(10, 13) EP_NQ(11, 14) EP_NQ(12, 17) "s_mov_b64 exec, -1\n"
+                 : [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]), [p8] "+v"(p[8]), [p9] "+v"(p[9]),
+                   [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p17] "+v"(p[17])
+                 : [q0] "s"(prm.qd[0]), [q1] "s"(prm.qd[1]), [q2] "s"(prm.qd[2]), [q3] "s"(prm.qd[3]), [q4] "s"(prm.qd[4]), [q5] "s"(prm.qd[5]),
+                   [q6] "s"(prm.qd[6]), [q7] "s"(prm.qd[7]), [q8] "s"(prm.qd[8]), [q9] "s"(prm.qd[9]), [q10] "s"(prm.qd[10]), [q11] "s"(prm.qd[11]),
+                   [q12] "s"(prm.qd[12]),
+                   [m3] "n"(1 << 3), [m4] "n"(1 << 4), [m5] "n"(1 << 5), [m6] "n"(1 << 6), [m7] "n"(1 << 7), [m8] "n"(1 << 8), [m9] "n"(1 << 9),
+                   [m10] "n"(1 << 10), [m11] "n"(1 << 11), [m12] "n"(1 << 12), [m13] "n"(1 << 13), [m14] "n"(1 << 14), [m17] "n"(1 << 17));
+#undef EP_NQ
+}
+__device__ __forceinline__ void noise_diag_exec(const DevParams<float>& prm, float (&p)[24]) {
+#define EP_NQ(K, ROW) "s_mov_b32 exec_lo, %[m" #ROW "]\n s_mov_b32 exec_hi, %[m" #ROW "]\n v_add_f32 %[p" #ROW "], %[p" #ROW "], %[q" #K "]\n"
+    asm volatile(EP_NQ(0, 3) EP_NQ(1, 4) EP_NQ(2, 5) EP_NQ(3, 6) EP_NQ(4, 7) EP_NQ(5, 8) EP_NQ(6, 9) EP_NQ(7, 10) EP_NQ(8, 11) EP_NQ(9, 12)
+                 EP_NQ(10, 13) EP_NQ(11, 14) EP_NQ(12, 17) "s_mov_b64 exec, -1\n"
+                 : [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]), [p8] "+v"(p[8]), [p9] "+v"(p[9]),
+                   [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p17] "+v"(p[17])
+                 : [q0] "s"(prm.qd[0]), [q1] "s"(prm.qd[1]), [q2] "s"(prm.qd[2]), [q3] "s"(prm.qd[3]), [q4] "s"(prm.qd[4]), [q5] "s"(prm.qd[5]),
+                   [q6] "s"(prm.qd[6]), [q7] "s"(prm.qd[7]), [q8] "s"(prm.qd[8]), [q9] "s"(prm.qd[9]), [q10] "s"(prm.qd[10]), [q11] "s"(prm.qd[11]),
+                   [q12] "s"(prm.qd[12]),
+                   [m3] "n"(1 << 3), [m4] "n"(1 << 4), [m5] "n"(1 << 5), [m6] "n"(1 << 6), [m7] "n"(1 << 7), [m8] "n"(1 << 8), [m9] "n"(1 << 9),
+                   [m10] "n"(1 << 10), [m11] "n"(1 << 11), [m12] "n"(1 << 12), [m13] "n"(1 << 13), [m14] "n"(1 << 14), [m17] "n"(1 << 17));
+#undef EP_NQ
+}
+
 template <typename T, bool PIN, bool GYRO = true, bool LANES32 = false>
 __device__ __forceinline__ void noise_rows(const DevParams<T>& prm, const T* sJ, const T* sN, int row, T (&p)[24]) {
     if constexpr (!PIN && LANES32) {
-        static_for<0, 12>([&](auto K) { add_in_row_lanes<3 + decltype(K)::value>(p[3 + decltype(K)::value], prm.qd[decltype(K)::value]); });
-        add_in_row_lanes<17>(p[17], prm.qd[12]);
+        noise_diag_exec(prm, p);            // (every lane of the wavefront is active where the predict runs)
     } else if (PIN) {      // diag(Q) of this instance sits in LDS (sN[0:13]); each lane needs the entry of its own row
         T qrow = T(0);
         if (row >= 3 && row < 15) qrow = sN[row - 3];
@@ -2790,7 +2821,7 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
         T o15 = v[15], o16 = v[16];
         J.template mac<J_DT>(o15, v[16]);
         J.template mac<J_DT>(o16, v[17]);
-        if (active) {
+        {   // (every lane stores: the idle lanes shadow row 23 -- the same words, the same values)
 #pragma unroll
             for (int k = 0; k < 9; ++k) lds_store1(dst + k, o[k]);
 #pragma unroll
@@ -2810,7 +2841,7 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
             static_for<0, 6>([&](auto K) { J.template mac<J_CM + 6 * r + decltype(K)::value>(u, v[9 + decltype(K)::value]); });
             o[r] = u;
         });
-        if (active) {
+        {   // (every lane stores: the idle lanes shadow row 23 -- the same words, the same values)
 #pragma unroll
             for (int r = 0; r < 3; ++r) lds_store1(dst + 18 + r, o[r]);
         }
@@ -2828,7 +2859,7 @@ __device__ __forceinline__ void fx_apply_store_dpp(const JRegs<T>& J, const T (&
             if (Q1 && r == 2) w += v[23];
             o[r] = w;
         });
-        if (active) {
+        {   // (every lane stores: the idle lanes shadow row 23 -- the same words, the same values)
 #pragma unroll
             for (int r = 0; r < 3; ++r) lds_store1(dst + 21 + r, o[r]);
         }
@@ -2903,6 +2934,74 @@ __device__ __forceinline__ void fx_apply_col_dpp(const JRegs<T>& J, const T* col
     }
 #pragma unroll
     for (int r = 0; r < 3; ++r) { o[18 + r] = u[r]; o[21 + r] = w[r]; }
+}
+// The store of a row into the packed-order LDS image (32 lanes per instance): element j exists in rows >= j only -- lanes
+// j..23 of each half, a constant per j -- so each element is one write under a constant execution mask written directly (two
+// scalar moves), with the element's offset in the instruction: the twin of gather_row_masked.  (As a predicated C++ store
+// each element cost a mask pair, a save and a restore of EXEC: 96 scalar instructions per row.)  va = LDS byte address of the
+// lane's packed row.  All lanes are active on entry; the writes are invisible to the compiler's counter logic: the block
+// waits for them itself.  (Text generated.)
+__device__ __forceinline__ void store_row_masked(unsigned va, const double (&p)[24]) {
+    asm volatile(
+        "s_mov_b32 exec_lo, 0x00ffffff\n s_mov_b32 exec_hi, 0x00ffffff\n ds_write_b64 %24, %0 offset:0\n"
+        "s_mov_b32 exec_lo, 0x00fffffe\n s_mov_b32 exec_hi, 0x00fffffe\n ds_write_b64 %24, %1 offset:8\n"
+        "s_mov_b32 exec_lo, 0x00fffffc\n s_mov_b32 exec_hi, 0x00fffffc\n ds_write_b64 %24, %2 offset:16\n"
+        "s_mov_b32 exec_lo, 0x00fffff8\n s_mov_b32 exec_hi, 0x00fffff8\n ds_write_b64 %24, %3 offset:24\n"
+        "s_mov_b32 exec_lo, 0x00fffff0\n s_mov_b32 exec_hi, 0x00fffff0\n ds_write_b64 %24, %4 offset:32\n"
+        "s_mov_b32 exec_lo, 0x00ffffe0\n s_mov_b32 exec_hi, 0x00ffffe0\n ds_write_b64 %24, %5 offset:40\n"
+        "s_mov_b32 exec_lo, 0x00ffffc0\n s_mov_b32 exec_hi, 0x00ffffc0\n ds_write_b64 %24, %6 offset:48\n"
+        "s_mov_b32 exec_lo, 0x00ffff80\n s_mov_b32 exec_hi, 0x00ffff80\n ds_write_b64 %24, %7 offset:56\n"
+        "s_mov_b32 exec_lo, 0x00ffff00\n s_mov_b32 exec_hi, 0x00ffff00\n ds_write_b64 %24, %8 offset:64\n"
+        "s_mov_b32 exec_lo, 0x00fffe00\n s_mov_b32 exec_hi, 0x00fffe00\n ds_write_b64 %24, %9 offset:72\n"
+        "s_mov_b32 exec_lo, 0x00fffc00\n s_mov_b32 exec_hi, 0x00fffc00\n ds_write_b64 %24, %10 offset:80\n"
+        "s_mov_b32 exec_lo, 0x00fff800\n s_mov_b32 exec_hi, 0x00fff800\n ds_write_b64 %24, %11 offset:88\n"
+        "s_mov_b32 exec_lo, 0x00fff000\n s_mov_b32 exec_hi, 0x00fff000\n ds_write_b64 %24, %12 offset:96\n"
+        "s_mov_b32 exec_lo, 0x00ffe000\n s_mov_b32 exec_hi, 0x00ffe000\n ds_write_b64 %24, %13 offset:104\n"
+        "s_mov_b32 exec_lo, 0x00ffc000\n s_mov_b32 exec_hi, 0x00ffc000\n ds_write_b64 %24, %14 offset:112\n"
+        "s_mov_b32 exec_lo, 0x00ff8000\n s_mov_b32 exec_hi, 0x00ff8000\n ds_write_b64 %24, %15 offset:120\n"
+        "s_mov_b32 exec_lo, 0x00ff0000\n s_mov_b32 exec_hi, 0x00ff0000\n ds_write_b64 %24, %16 offset:128\n"
+        "s_mov_b32 exec_lo, 0x00fe0000\n s_mov_b32 exec_hi, 0x00fe0000\n ds_write_b64 %24, %17 offset:136\n"
+        "s_mov_b32 exec_lo, 0x00fc0000\n s_mov_b32 exec_hi, 0x00fc0000\n ds_write_b64 %24, %18 offset:144\n"
+        "s_mov_b32 exec_lo, 0x00f80000\n s_mov_b32 exec_hi, 0x00f80000\n ds_write_b64 %24, %19 offset:152\n"
+        "s_mov_b32 exec_lo, 0x00f00000\n s_mov_b32 exec_hi, 0x00f00000\n ds_write_b64 %24, %20 offset:160\n"
+        "s_mov_b32 exec_lo, 0x00e00000\n s_mov_b32 exec_hi, 0x00e00000\n ds_write_b64 %24, %21 offset:168\n"
+        "s_mov_b32 exec_lo, 0x00c00000\n s_mov_b32 exec_hi, 0x00c00000\n ds_write_b64 %24, %22 offset:176\n"
+        "s_mov_b32 exec_lo, 0x00800000\n s_mov_b32 exec_hi, 0x00800000\n ds_write_b64 %24, %23 offset:184\n"
+        "s_mov_b64 exec, -1\n s_waitcnt lgkmcnt(0)\n"
+        :
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]), "v"(p[16]), "v"(p[17]), "v"(p[18]), "v"(p[19]), "v"(p[20]), "v"(p[21]), "v"(p[22]), "v"(p[23]), "v"(va)
+        : "memory");
+}
+__device__ __forceinline__ void store_row_masked(unsigned va, const float (&p)[24]) {
+    asm volatile(
+        "s_mov_b32 exec_lo, 0x00ffffff\n s_mov_b32 exec_hi, 0x00ffffff\n ds_write_b32 %24, %0 offset:0\n"
+        "s_mov_b32 exec_lo, 0x00fffffe\n s_mov_b32 exec_hi, 0x00fffffe\n ds_write_b32 %24, %1 offset:4\n"
+        "s_mov_b32 exec_lo, 0x00fffffc\n s_mov_b32 exec_hi, 0x00fffffc\n ds_write_b32 %24, %2 offset:8\n"
+        "s_mov_b32 exec_lo, 0x00fffff8\n s_mov_b32 exec_hi, 0x00fffff8\n ds_write_b32 %24, %3 offset:12\n"
+        "s_mov_b32 exec_lo, 0x00fffff0\n s_mov_b32 exec_hi, 0x00fffff0\n ds_write_b32 %24, %4 offset:16\n"
+        "s_mov_b32 exec_lo, 0x00ffffe0\n s_mov_b32 exec_hi, 0x00ffffe0\n ds_write_b32 %24, %5 offset:20\n"
+        "s_mov_b32 exec_lo, 0x00ffffc0\n s_mov_b32 exec_hi, 0x00ffffc0\n ds_write_b32 %24, %6 offset:24\n"
+        "s_mov_b32 exec_lo, 0x00ffff80\n s_mov_b32 exec_hi, 0x00ffff80\n ds_write_b32 %24, %7 offset:28\n"
+        "s_mov_b32 exec_lo, 0x00ffff00\n s_mov_b32 exec_hi, 0x00ffff00\n ds_write_b32 %24, %8 offset:32\n"
+        "s_mov_b32 exec_lo, 0x00fffe00\n s_mov_b32 exec_hi, 0x00fffe00\n ds_write_b32 %24, %9 offset:36\n"
+        "s_mov_b32 exec_lo, 0x00fffc00\n s_mov_b32 exec_hi, 0x00fffc00\n ds_write_b32 %24, %10 offset:40\n"
+        "s_mov_b32 exec_lo, 0x00fff800\n s_mov_b32 exec_hi, 0x00fff800\n ds_write_b32 %24, %11 offset:44\n"
+        "s_mov_b32 exec_lo, 0x00fff000\n s_mov_b32 exec_hi, 0x00fff000\n ds_write_b32 %24, %12 offset:48\n"
+        "s_mov_b32 exec_lo, 0x00ffe000\n s_mov_b32 exec_hi, 0x00ffe000\n ds_write_b32 %24, %13 offset:52\n"
+        "s_mov_b32 exec_lo, 0x00ffc000\n s_mov_b32 exec_hi, 0x00ffc000\n ds_write_b32 %24, %14 offset:56\n"
+        "s_mov_b32 exec_lo, 0x00ff8000\n s_mov_b32 exec_hi, 0x00ff8000\n ds_write_b32 %24, %15 offset:60\n"
+        "s_mov_b32 exec_lo, 0x00ff0000\n s_mov_b32 exec_hi, 0x00ff0000\n ds_write_b32 %24, %16 offset:64\n"
+        "s_mov_b32 exec_lo, 0x00fe0000\n s_mov_b32 exec_hi, 0x00fe0000\n ds_write_b32 %24, %17 offset:68\n"
+        "s_mov_b32 exec_lo, 0x00fc0000\n s_mov_b32 exec_hi, 0x00fc0000\n ds_write_b32 %24, %18 offset:72\n"
+        "s_mov_b32 exec_lo, 0x00f80000\n s_mov_b32 exec_hi, 0x00f80000\n ds_write_b32 %24, %19 offset:76\n"
+        "s_mov_b32 exec_lo, 0x00f00000\n s_mov_b32 exec_hi, 0x00f00000\n ds_write_b32 %24, %20 offset:80\n"
+        "s_mov_b32 exec_lo, 0x00e00000\n s_mov_b32 exec_hi, 0x00e00000\n ds_write_b32 %24, %21 offset:84\n"
+        "s_mov_b32 exec_lo, 0x00c00000\n s_mov_b32 exec_hi, 0x00c00000\n ds_write_b32 %24, %22 offset:88\n"
+        "s_mov_b32 exec_lo, 0x00800000\n s_mov_b32 exec_hi, 0x00800000\n ds_write_b32 %24, %23 offset:92\n"
+        "s_mov_b64 exec, -1\n s_waitcnt lgkmcnt(0)\n"
+        :
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10]), "v"(p[11]), "v"(p[12]), "v"(p[13]), "v"(p[14]), "v"(p[15]), "v"(p[16]), "v"(p[17]), "v"(p[18]), "v"(p[19]), "v"(p[20]), "v"(p[21]), "v"(p[22]), "v"(p[23]), "v"(va)
+        : "memory");
 }
 // (row >= J) ? a : b for the 32-lanes-per-instance layout, where row = min(lane & 31, 23): the lanes with
 // row >= J are a compile-time constant, so the select takes its condition from a scalar register pair instead of a
@@ -3589,11 +3688,7 @@ __device__ __forceinline__ void cov_rows_body(const StepArgs& a_in, const DevPar
         // exists in rows >= j only: a constant set of lanes per j.
         const int st_ = row < 12 ? 25 * row : 26 * (23 - row) + 1;
         T* rp_ = sB + st_;
-        static_for<0, 24>([&](auto JJ) {
-            constexpr int j = decltype(JJ)::value;
-            constexpr unsigned long long m32 = (0x00ffffffull >> j) << j, m64 = m32 | (m32 << 32);
-            if (__builtin_amdgcn_inverse_ballot_w64(m64)) lds_store1(rp_ + j, p[j]);
-        });
+        store_row_masked((unsigned)(size_t)(__attribute__((address_space(3))) T*)rp_, p);
         gsync();
         if (valid && !(WAVE && p_keep)) {
             // (wave-uniform base + unsigned 32-bit lane offset, the piece's constant in the offset field -- as for the loads)
