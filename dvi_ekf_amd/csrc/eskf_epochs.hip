@@ -1007,7 +1007,7 @@ static int n_compute_units() {
 // and the launcher leaves the run to it unless DVI_ESKF_EPOCHS=1 asks for this kernel; 0 = the kernel serves nothing.
 // fp32, two pairs per covariance wavefront (PP = 2; 32 / 40 / 48 instances per block): the producers' lanes are used twice
 // as well, the covariance wavefronts' own work is the same instructions.  One generation of 32-instance blocks takes
-// 101.6 us per frame whatever its fill (B = 8 192: 2.69e9 IMU steps/s against 2.57e9 epoch by epoch), 40 / 48 per block
+// 97-101 us per frame whatever its fill (B = 8 192: 2.7-2.8e9 IMU steps/s against 2.57-2.6e9 epoch by epoch), 40 / 48 per block
 // 132 / 133 us (B = 10 240 / 12 288: level with the epoch-by-epoch path or behind it): the launcher takes PP = 2 where a
 // generation of 32-instance blocks is at least nine tenths full, B in [29 CUs, 32 CUs].  (DVI_ESKF_EPOCHS_PP=1 | 2 pins it.)
 // Returns the instances per block, 2 NC PP (PP = 2 with NC = 8 | 10 | 12, fp32 only: 32 | 40 | 48 instances).
