@@ -940,11 +940,13 @@ __device__ __forceinline__ int wave_role(int wave) {       // 0 RA, 1 RB, 2 JA, 
     if constexpr (NC == 2) return wave < 2 ? 4 + wave : wave < 4 ? wave - 2 : wave < 6 ? -1 : wave - 4;
     else return wave;
 }
-#ifndef ESKF_EP_F32_WAVES
-#define ESKF_EP_F32_WAVES 4
+// wavefronts per SIMD the kernel is made for: those of ONE block (a CU never holds two: the launcher gives every CU at most one
+// block, and from NC = 8 on a second one would not fit the LDS) -- 256 registers per lane up to NC = 4, 168 at NC = 8, 128 above
+#ifndef ESKF_EP_MIN_WAVES
+#define ESKF_EP_MIN_WAVES(NC) ((Waves<NC>::N + 3) / 4)
 #endif
 template <typename T, int NC, int PP>
-__global__ __launch_bounds__(Waves<NC>::N * 64, (sizeof(T) == 4 && NC == 8 && PP == 1) ? ESKF_EP_F32_WAVES : PP > 1 ? (Waves<NC>::N + 3) / 4 : 4)
+__global__ __launch_bounds__(Waves<NC>::N * 64, ESKF_EP_MIN_WAVES(NC))
 void eskf_epochs_kernel(EpochsArgs A, DevParams<T> prm) {
     using L = ep::Lay<T, NC, PP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
