@@ -29,7 +29,7 @@ def close(a, b, what, tol):
         assert float(np.abs(x[fin] - y[fin]).max()) <= tol * s, (what, k, float(np.abs(x[fin] - y[fin]).max()), s)
 
 
-def main(B, dtype, n_pred, frozen, hold):
+def main(B, dtype, n_pred, frozen, hold, rows_closeness=True):
     dev = torch.device("cuda", 0)
     E = len(n_pred)
     total = int(sum(n_pred))
@@ -134,7 +134,7 @@ def main(B, dtype, n_pred, frozen, hold):
         # (ii) the rows of the samples in between (propagated states) against the reference's call sequence (predict, log row, ...,
         #      update, log row) on a handle that keeps its Jacobians and therefore never takes the one-launch path: another
         #      rounding sequence (P is symmetrised after every predict there), compared where the schedule leaves that benign
-        if exact:
+        if exact and rows_closeness:      # (tools/soak_epochs.py skips it: long random schedules of unfrozen instances amplify a last bit past any bound)
             f4 = snap.clone()
             f4.keep_jacobians(True)
             _, rows_ref = f4.run_epochs(n_pred, dt, om, acc, pos, quat, notch, t_pred=t_pred)
