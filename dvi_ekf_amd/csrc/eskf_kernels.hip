@@ -3894,8 +3894,14 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const DevParams<T>
     }
 }
 
+// wavefronts per SIMD the one-launch step is made for: fp64 four (128 registers, two blocks per CU -- their LDS); fp32 six
+// (80 registers, ten of them spilled: three blocks per CU -- config #3, predict-only launches at B = 1 048 576, 0.589 -> 0.608 of
+// the roof, same box twice)
+#ifndef ESKF_STEP_WAVES
+#define ESKF_STEP_WAVES(T) (sizeof(T) == 4 ? 6 : 4)
+#endif
 template <typename T, int ROUNDS, bool PIN = false>
-__global__ __launch_bounds__(512, 4) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
+__global__ __launch_bounds__(512, ESKF_STEP_WAVES(T)) void eskf_step_kernel(StepArgs a, DevParams<T> prm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // (the wavefront's number as a SCALAR: everything derived from it -- the role, the image address, the pair index and
     //  with it the wave-uniform bases of the covariance body's addressing -- stays in scalar registers)
