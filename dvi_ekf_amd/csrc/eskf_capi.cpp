@@ -711,7 +711,12 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
         const size_t es_ = elem_size(h->dtype);
         const size_t B_ = (size_t)h->B;
         const size_t nl = (size_t)((sc->rows_instances > 0 && sc->rows_instances < h->B) ? sc->rows_instances : h->B);
-        if (nl != B_) return DVI_ESKF_EINVAL;      // (dvi_eskf_log_rows forms the rows of the whole batch: a subset needs the one-launch path)
+        auto log_row = [&](size_t gg) -> int {        // row gg of the run: the flushed state of the first nl instances
+            DeviceGuard dg(h->device);
+            if (!dg.ok || flush_pending(h, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
+            return eskf::launch_log_rows(h->dtype, h->B, (int64_t)nl, h->d_x, sc->t_pred[gg], static_cast<char*>(sc->rows_pred_out) + gg * nl * 30 * es_,
+                                         (hipStream_t)stream) == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
+        };
         const size_t dt_row_ = (sc->dt_per_instance ? B_ : 1) * es_, imu_row_ = (sc->imu_per_instance ? B_ : 1) * 3 * es_;
         const size_t mrow_ = sc->meas_per_instance ? B_ : 1;
         size_t g = 0;
@@ -721,7 +726,7 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
                                      static_cast<const char*>(sc->acc) + g * imu_row_, sc->imu_per_instance, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
                                      stream, (e == 0 && k == 0) ? src : nullptr);
                 if (rc != DVI_ESKF_OK) return rc;
-                rc = dvi_eskf_log_rows(h, sc->t_pred[g], static_cast<char*>(sc->rows_pred_out) + g * B_ * 30 * es_, stream);
+                rc = log_row(g);
                 if (rc != DVI_ESKF_OK) return rc;
             }
             int rc = step_common(h, 0, 1, nullptr, 0, nullptr, nullptr, 0, static_cast<const char*>(sc->pos) + (size_t)e * mrow_ * 3 * es_,
@@ -729,7 +734,7 @@ int run_epochs_impl(dvi_eskf* h, dvi_eskf* src, const dvi_eskf_schedule* sc, voi
                                  sc->meas_per_instance, nullptr, sc->status ? sc->status + (size_t)e * B_ : nullptr, stream, (e == 0 && sc->n_pred[0] == 0) ? src : nullptr);
             if (rc != DVI_ESKF_OK) return rc;
             if (g > 0) {
-                rc = dvi_eskf_log_rows(h, sc->t_pred[g - 1], static_cast<char*>(sc->rows_pred_out) + (g - 1) * B_ * 30 * es_, stream);
+                rc = log_row(g - 1);
                 if (rc != DVI_ESKF_OK) return rc;
             }
         }
@@ -931,7 +936,7 @@ int dvi_eskf_log_rows(dvi_eskf* h, double t, void* rows_out, void* stream) {
     DeviceGuard g(h->device);
     if (!g.ok) return DVI_ESKF_EHIP;
     if (flush_pending(h, (hipStream_t)stream) != DVI_ESKF_OK) return DVI_ESKF_EHIP;
-    hipError_t e = eskf::launch_log_rows(h->dtype, h->B, h->d_x, t, rows_out, (hipStream_t)stream);
+    hipError_t e = eskf::launch_log_rows(h->dtype, h->B, h->B, h->d_x, t, rows_out, (hipStream_t)stream);
     return e == hipSuccess ? DVI_ESKF_OK : DVI_ESKF_EHIP;
 }
 

@@ -155,7 +155,8 @@ hipError_t launch_imu(int dtype, int64_t n, const void* R_WC, const void* om, co
                       const void* notch, int notch_stride, const void* p_CW, const void* v_CW, void* om_B, void* acc_B,
                       void* p_BW, void* R_WB, void* v_BW, const double* dofs6, const HostParams& hp, hipStream_t stream);
 
-hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream);
+// rows [n_log][30] of the batch's first n_log instances (n_log <= B) from the state record xs [36][B]
+hipError_t launch_log_rows(int dtype, int64_t B, int64_t n_log, const void* xs, double t, void* rows, hipStream_t stream);
 // rows [n_rows][n_log][30] from the snapshots xlog [n_rows][26][n_log] of a run (EpochsArgs::xlog) -- the last row from the state
 // record xs [36][B] itself (flushed) -- with the time stamps t_rows (device, double [n_rows])
 hipError_t launch_log_rows_run(int dtype, int64_t n_rows, int64_t n_log, const void* xlog, const void* xs, int64_t B, const double* t_rows,

@@ -4136,9 +4136,9 @@ __device__ __forceinline__ void euler_xyz_deg(const T* q, T* e) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void eskf_log_rows_kernel(int64_t B, const T* xs, T tstamp, T* rows) {
-    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+__global__ __launch_bounds__(256) void eskf_log_rows_kernel(int64_t B, int64_t n_log, const T* xs, T tstamp, T* rows) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (the rows of the batch's first n_log instances)
+    if (b >= n_log) return;
     State<T> s;
     load_state(xs, B, b, s);
     T* r = rows + b * 30;
@@ -4668,13 +4668,14 @@ hipError_t launch_jacobians(int dtype, int64_t B, const void* J, int ip, void* F
     return hipGetLastError();
 }
 
-hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double t, void* rows, hipStream_t stream) {
-    if (B <= 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((B + 255) / 256);
+hipError_t launch_log_rows(int dtype, int64_t B, int64_t n_log, const void* xs, double t, void* rows, hipStream_t stream) {
+    if (B <= 0 || n_log <= 0) return hipSuccess;
+    if (n_log > B) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((n_log + 255) / 256);
     if (dtype == 0)
-        hipLaunchKernelGGL(eskf_log_rows_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, (const double*)xs, t, (double*)rows);
+        hipLaunchKernelGGL(eskf_log_rows_kernel<double>, dim3(blocks), dim3(256), 0, stream, B, n_log, (const double*)xs, t, (double*)rows);
     else
-        hipLaunchKernelGGL(eskf_log_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, (const float*)xs, (float)t, (float*)rows);
+        hipLaunchKernelGGL(eskf_log_rows_kernel<float>, dim3(blocks), dim3(256), 0, stream, B, n_log, (const float*)xs, (float)t, (float*)rows);
     return hipGetLastError();
 }
 

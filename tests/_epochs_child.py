@@ -35,7 +35,7 @@ def main(B, dtype, n_pred, frozen, hold, rows_closeness=True):
     total = int(sum(n_pred))
     H = 8
     wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, dtype=dtype, frozen=frozen)
-    f = wl.make_filter()
+    f = wl.make_filter(dtype=dtype)
     if not hold:
         # (frozen DOFs zeroed after every predict, Filter.py:243-245: the v1-literal plumbing)
         from dvi_ekf_amd.batch import BatchedESKF
@@ -130,7 +130,9 @@ def main(B, dtype, n_pred, frozen, hold, rows_closeness=True):
             want = gk.log_rows(float(t_pred[o - 1]))[:nl]
             if e + 1 < E and n_pred[e + 1] == 0:
                 continue                            # (the next epoch has no sample of its own: its update replaces this row once more)
-            assert torch.equal(rows[o - 1], want) or bool(torch.isnan(want).any()), ("row of update", e)
+            if not (torch.equal(rows[o - 1], want) or bool(torch.isnan(want).any())):
+                d = (rows[o - 1].double() - want.double()).abs()
+                raise AssertionError(("row of update", e, "max abs", float(d.max()), "where (instance, column)", torch.nonzero(d > 0)[:8].tolist()))
         # (ii) the rows of the samples in between (propagated states) against the reference's call sequence (predict, log row, ...,
         #      update, log row) on a handle that keeps its Jacobians and therefore never takes the one-launch path: another
         #      rounding sequence (P is symmetrised after every predict there), compared where the schedule leaves that benign

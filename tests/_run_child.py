@@ -20,7 +20,7 @@ def same(a, b, what):
 def main(B, dtype, pin=False, H=6):
     dev = torch.device("cuda", 0)
     wl = monte_carlo_pairs(B, horizon=H, seed=4, device=dev, dtype=dtype)
-    f = wl.make_filter()
+    f = wl.make_filter(dtype=dtype)
     if pin:     # per-instance noise records (a tuning population): the one-launch kernels with the 664-word images
         rng = np.random.default_rng(5)
         q13 = np.tile(np.diag(wl.Q), (B, 1)) * rng.uniform(0.5, 2.0, (B, 13))

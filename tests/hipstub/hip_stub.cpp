@@ -190,8 +190,8 @@ hipError_t launch_unpack(int dtype, int64_t B, const void* xs, const void* Ppk, 
 }
 hipError_t launch_imu(int, int64_t, const void*, const void*, const void*, const void*, const void*, int, const void*, const void*, void*, void*, void*, void*, void*,
                       const double*, const HostParams&, hipStream_t) { ++g_launches; return hipSuccess; }
-hipError_t launch_log_rows(int dtype, int64_t B, const void* xs, double, void* rows, hipStream_t) {
-    rd(xs, 36 * (size_t)B * es_of(dtype)); wr(rows, (size_t)B * 30 * es_of(dtype)); ++g_launches; return hipSuccess;
+hipError_t launch_log_rows(int dtype, int64_t B, int64_t n_log, const void* xs, double, void* rows, hipStream_t) {
+    rd(xs, 36 * (size_t)B * es_of(dtype)); wr(rows, (size_t)n_log * 30 * es_of(dtype)); ++g_launches; return hipSuccess;
 }
 hipError_t launch_update_mse(int dtype, int64_t B, const void* xs, const double* cam6, const double* imu6, void* mse, hipStream_t) {
     rd(xs, 36 * (size_t)B * es_of(dtype)); rd(cam6, 48); if (imu6) rd(imu6, 48); wr(mse, (size_t)B * es_of(dtype)); ++g_launches; return hipSuccess;

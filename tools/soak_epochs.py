@@ -21,15 +21,21 @@ sys.argv = saved
 rng = np.random.default_rng(seed)
 t_end, n = time.time() + secs, 0
 while time.time() < t_end:
-    B = int(rng.choice([1, 3, 5, 64, 130, 515, 1000, 1500, 2500, 4097, 6144]))
+    B = int(rng.choice([1, 3, 5, 64, 130, 515, 1000, 1500, 2500, 4097, 6144, 7424, 8192]))
     dtype = torch.float64 if rng.random() < 0.5 else torch.float32
+    if B > 6144 and dtype == torch.float64 and os.environ.get("DVI_ESKF_EPOCHS") != "1":
+        continue                # (not the long-horizon kernel's by default: the scenario's bitwise checks are about that kernel)
     E = int(rng.integers(1, 9))
     sched = [int(v) for v in rng.choice([0, 2, 3, 5, 9, 17, 33], size=E)]
     if sum(sched) == 0:
         sched[0] = 2
     frozen = tuple(int(v) for v in rng.integers(0, 2, 6)) if rng.random() < 0.3 else (0,) * 6
     hold = bool(rng.random() < 0.7)
-    child.main(B, dtype, sched, frozen, hold, rows_closeness=False)
+    try:
+        child.main(B, dtype, sched, frozen, hold, rows_closeness=False)
+    except AssertionError:
+        print("soak: FAILED at B %d %s schedule %s frozen %s hold %s" % (B, str(dtype)[-7:], sched, frozen, hold), flush=True)
+        raise
     n += 1
     if n % 10 == 0:
         print("soak: %d runs bitwise equal (last: B %d %s %s)" % (n, B, str(dtype)[-7:], sched), flush=True)
